@@ -1,0 +1,555 @@
+// er_api.cpp -- implementation of the C ABI declared in include/eleven_hip.h.
+// Host side of the device boundary: the MI355X replacement for dev_Scene's constructor,
+// copy_scene, renderSetup, kernel_render_enqueue and RenderingManager::get_pass
+// (reference src/kernel.cpp:244-266,651-706; src/SYCLCopy.cpp:3-104; src/Managers.cpp:287-302).
+// There is NO CPU fallback: without a usable HIP device every compute entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/eleven_hip.h"
+#include "er_bvh.h"
+#include "er_device.h"
+#include "er_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(e__ == hipErrorOutOfMemory ? ER_ERR_OOM : ER_ERR_HIP,                           \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));                            \
+    } while (0)
+
+struct HostTex {
+    int32_t width, height, channels, filter;
+    std::vector<float> data;
+};
+
+// Texture::getValueFromCoordinates, reference src/Texture.cpp:172-200 (host copy, used by the CDF)
+void host_tex_coords(const HostTex& t, int x, int y, float out[3]) {
+    x %= t.width;
+    y %= t.height;
+    if (x < 0) x *= -1;
+    if (y < 0) y *= -1;
+    out[0] = out[1] = out[2] = 0.0f;
+    const float* d = t.data.data();
+    if (t.channels == 1) {
+        out[0] = out[1] = out[2] = d[y * t.width + x];
+    } else if (t.channels == 2) {
+        out[0] = d[t.channels * (y * t.width + x) + 0];
+        out[1] = d[t.channels * (y * t.width + x) + 1];
+    } else if (t.channels >= 3) {
+        out[0] = d[t.channels * (y * t.width + x) + 0];
+        out[1] = d[t.channels * (y * t.width + x) + 1];
+        out[2] = d[t.channels * (y * t.width + x) + 2];
+    }
+}
+
+// HDRI::generateCDF, reference src/HDRI.cpp:62-83 (host preparation, same float sequence)
+void host_generate_cdf(const HostTex& t, std::vector<float>& cdf, float& radianceSum) {
+    int c = 0;
+    radianceSum = 0;
+    cdf.assign((size_t)t.width * t.height + 1, 0.0f);
+    float p[3];
+    for (int j = 0; j < t.height; j++)
+        for (int i = 0; i < t.width; i++) {
+            host_tex_coords(t, i, j, p);
+            radianceSum += p[0] + p[1] + p[2];
+        }
+    for (int j = 0; j < t.height; j++)
+        for (int i = 0; i < t.width; i++) {
+            host_tex_coords(t, i, j, p);
+            cdf[c + 1] = cdf[c] + (p[0] + p[1] + p[2]) / radianceSum;
+            c++;
+        }
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+}  // namespace
+
+struct ErScene {
+    // host copy of the description
+    uint32_t tri_count = 0;
+    std::vector<float> vertices, normals, tangents, uvs, tangent_sign;
+    std::vector<int32_t> material_id;
+    std::vector<ErMaterial> materials;
+    std::vector<HostTex> textures;
+    HostTex hdri_tex;
+    std::vector<float> hdri_cdf;
+    float hdri_radiance_sum = 0;
+    ErCamera camera;
+    std::vector<ErPointLight> point_lights;
+    uint32_t x_res = 0, y_res = 0;
+
+    // render state
+    bool begun = false;
+    int device = 0;
+    ErRenderParams params{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timing_open = false;
+    DevScene dev{};
+    ErAccelInfo accel{};
+    DevBuf<float4> d_nodes, d_isect, d_attr, d_passes;
+    DevBuf<ErMaterial> d_materials;
+    DevBuf<DevTex> d_textures;
+    DevBuf<float> d_tex_pool, d_cdf;
+    DevBuf<uint32_t> d_samples, d_rng, d_owned;
+    DevBuf<DevCounters> d_counters;
+    std::map<uint32_t, DevBuf<uint32_t>> d_rank_tiles;   // tile lists of other ranks (for unpack)
+    std::mutex mtx;
+
+    std::vector<uint32_t> tiles_of(uint32_t rank, uint32_t world) const {
+        std::vector<uint32_t> t;
+        uint32_t tiles_x = (x_res + ER_TILE - 1) / ER_TILE, tiles_y = (y_res + ER_TILE - 1) / ER_TILE;
+        for (uint32_t ty = 0; ty < tiles_y; ty++)
+            for (uint32_t tx = 0; tx < tiles_x; tx++)
+                if ((tx + ty) % world == rank) t.push_back(ty * tiles_x + tx);
+        return t;
+    }
+    void release_device() {
+        d_nodes.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_materials.release();
+        d_textures.release(); d_tex_pool.release(); d_cdf.release(); d_samples.release(); d_rng.release();
+        d_owned.release(); d_counters.release();
+        for (auto& kv : d_rank_tiles) kv.second.release();
+        d_rank_tiles.clear();
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        if (ev_stop) (void)hipEventDestroy(ev_stop);
+        if (stream) (void)hipStreamDestroy(stream);
+        ev_start = ev_stop = nullptr;
+        stream = nullptr;
+        begun = false;
+        timing_open = false;
+    }
+};
+
+namespace {
+
+template <class T>
+int upload(DevBuf<T>& b, const void* src, size_t count, hipStream_t s) {
+    b.release();
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void**)&b.p, bytes));
+    b.n = count;
+    if (count && src) HIP_TRY(hipMemcpyAsync(b.p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    return ER_OK;
+}
+
+int copy_tex(const ErTexture& in, HostTex& out, const char* what) {
+    if (in.width <= 0 || in.height <= 0 || in.channels < 0 || (in.channels > 0 && !in.data))
+        return fail(ER_ERR_INVALID_ARG, std::string("bad texture: ") + what);
+    out.width = in.width; out.height = in.height; out.channels = in.channels; out.filter = in.filter;
+    size_t n = (size_t)in.width * in.height * in.channels;
+    out.data.assign(in.data, in.data + n);
+    return ER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int er_abi_version(void) { return ER_ABI_VERSION; }
+const char* er_last_error(void) { return g_err.c_str(); }
+
+int er_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int er_device_info(int index, ErDeviceInfo* out) {
+    if (!out) return fail(ER_ERR_INVALID_ARG, "er_device_info: out is NULL");
+    int n = er_device_count();
+    if (index < 0 || index >= n) return fail(ER_ERR_NO_DEVICE, "er_device_info: no such HIP device");
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, index));
+    memset(out, 0, sizeof(*out));
+    snprintf(out->name, sizeof(out->name), "%s", p.name);
+    snprintf(out->platform, sizeof(out->platform), "AMD HIP");
+    snprintf(out->arch, sizeof(out->arch), "%s", p.gcnArchName);
+    out->memory_bytes = p.totalGlobalMem;
+    out->compute_units = (uint32_t)p.multiProcessorCount;
+    out->compatible = strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+    return ER_OK;
+}
+
+int er_device_find(const char* selector) {
+    if (!selector) return fail(ER_ERR_INVALID_ARG, "er_device_find: selector is NULL");
+    int n = er_device_count();
+    for (int i = 0; i < n; i++) {
+        ErDeviceInfo info;
+        if (er_device_info(i, &info) != ER_OK) continue;
+        std::string s = std::string(info.name) + "|" + info.platform;   // NameSelector, reference src/Managers.cpp:201
+        if (s == selector) return i;
+    }
+    return fail(ER_ERR_NO_DEVICE, std::string("er_device_find: no device matches '") + selector + "'");
+}
+
+int er_scene_create(const ErSceneDesc* d, ErScene** out) {
+    if (!d || !out) return fail(ER_ERR_INVALID_ARG, "er_scene_create: NULL argument");
+    *out = nullptr;
+    if (d->x_res == 0 || d->y_res == 0) return fail(ER_ERR_INVALID_ARG, "er_scene_create: zero resolution");
+    if ((uint64_t)d->x_res * d->y_res > 0x7fffffffull) return fail(ER_ERR_INVALID_ARG, "er_scene_create: resolution too large");
+    if (d->tri_count >= (1u << 28)) return fail(ER_ERR_INVALID_ARG, "er_scene_create: too many triangles");
+    if (d->tri_count && (!d->vertices || !d->normals || !d->tangents || !d->uvs || !d->tangent_sign || !d->material_id))
+        return fail(ER_ERR_INVALID_ARG, "er_scene_create: triangle arrays missing");
+    if (d->material_count == 0 || !d->materials) return fail(ER_ERR_INVALID_ARG, "er_scene_create: at least one material is required");
+    ErScene* s = new (std::nothrow) ErScene();
+    if (!s) return fail(ER_ERR_OOM, "er_scene_create: out of host memory");
+    size_t n = d->tri_count;
+    s->tri_count = d->tri_count;
+    if (n) {
+        s->vertices.assign(d->vertices, d->vertices + n * 9);
+        s->normals.assign(d->normals, d->normals + n * 9);
+        s->tangents.assign(d->tangents, d->tangents + n * 9);
+        s->uvs.assign(d->uvs, d->uvs + n * 6);
+        s->tangent_sign.assign(d->tangent_sign, d->tangent_sign + n);
+        s->material_id.assign(d->material_id, d->material_id + n);
+    }
+    for (size_t i = 0; i < n; i++)
+        if (s->material_id[i] < 0 || (uint32_t)s->material_id[i] >= d->material_count) {
+            delete s;
+            return fail(ER_ERR_INVALID_ARG, "er_scene_create: material_id out of range");
+        }
+    s->materials.assign(d->materials, d->materials + d->material_count);
+    for (const ErMaterial& m : s->materials) {
+        const int32_t ids[7] = {m.albedo_tex, m.emission_tex, m.roughness_tex, m.metallic_tex, m.normal_tex, m.opacity_tex, m.transmission_tex};
+        for (int32_t id : ids)
+            if (id >= (int32_t)d->texture_count) {
+                delete s;
+                return fail(ER_ERR_INVALID_ARG, "er_scene_create: texture id out of range");
+            }
+    }
+    s->textures.resize(d->texture_count);
+    for (uint32_t i = 0; i < d->texture_count; i++) {
+        int rc = copy_tex(d->textures[i], s->textures[i], "scene texture");
+        if (rc != ER_OK) { delete s; return rc; }
+    }
+    int rc = copy_tex(d->hdri.texture, s->hdri_tex, "hdri");
+    if (rc != ER_OK) { delete s; return rc; }
+    if (d->hdri.cdf) {
+        s->hdri_cdf.assign(d->hdri.cdf, d->hdri.cdf + (size_t)s->hdri_tex.width * s->hdri_tex.height + 1);
+        s->hdri_radiance_sum = d->hdri.radiance_sum;
+    } else {
+        host_generate_cdf(s->hdri_tex, s->hdri_cdf, s->hdri_radiance_sum);
+    }
+    s->camera = d->camera;
+    if (d->point_light_count && d->point_lights) s->point_lights.assign(d->point_lights, d->point_lights + d->point_light_count);
+    s->x_res = d->x_res;
+    s->y_res = d->y_res;
+    *out = s;
+    return ER_OK;
+}
+
+void er_scene_destroy(ErScene* s) {
+    if (!s) return;
+    if (s->begun || s->stream) {
+        (void)hipSetDevice(s->device);
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+    }
+    s->release_device();
+    delete s;
+}
+
+int er_render_begin(ErScene* s, const ErRenderParams* p) {
+    if (!s || !p) return fail(ER_ERR_INVALID_ARG, "er_render_begin: NULL argument");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    uint32_t world = p->world ? p->world : 1;
+    if (p->rank >= world) return fail(ER_ERR_INVALID_ARG, "er_render_begin: rank >= world");
+    if (p->flags & ER_FLAG_POINT_LIGHTS) return fail(ER_ERR_INVALID_ARG, "er_render_begin: ER_FLAG_POINT_LIGHTS is not implemented yet");
+    int ndev = er_device_count();
+    if (ndev <= 0) return fail(ER_ERR_NO_DEVICE, "er_render_begin: no HIP device available (there is no CPU fallback)");
+    if (p->device < 0 || p->device >= ndev) return fail(ER_ERR_NO_DEVICE, "er_render_begin: device ordinal out of range");
+    {
+        // the library carries gfx950 code objects only; launching on anything else faults inside the runtime
+        ErDeviceInfo info;
+        int irc = er_device_info(p->device, &info);
+        if (irc != ER_OK) return irc;
+        if (!info.compatible) return fail(ER_ERR_NO_DEVICE, std::string("er_render_begin: device arch '") + info.arch + "' is not gfx950");
+    }
+    if (s->begun || s->stream) {
+        (void)hipSetDevice(s->device);
+        if (s->stream) (void)hipStreamSynchronize(s->stream);
+        s->release_device();
+    }
+    s->device = p->device;
+    s->params = *p;
+    s->params.world = world;
+    if (s->params.max_bounces == 0) s->params.max_bounces = 5;   // the literal of reference src/kernel.cpp:508
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&s->ev_start));
+    HIP_TRY(hipEventCreate(&s->ev_stop));
+
+    // ---- acceleration structure (host) ----
+    ErBvhBuild bvh;
+    er_build_bvh(s->vertices.data(), s->normals.data(), s->tri_count, 0, &bvh);
+    if (bvh.max_depth > ER_BVH_MAX_DEPTH) return fail(ER_ERR_STATE, "er_render_begin: BVH deeper than the traversal stack");
+    size_t n = s->tri_count;
+    std::vector<ErTriIsect> isect(n);
+    std::vector<ErTriAttr> attr(n);
+    for (size_t slot = 0; slot < n; slot++) {
+        uint32_t id = bvh.slot_to_tri[slot];
+        const float* v = &s->vertices[(size_t)id * 9];
+        ErTriIsect& r = isect[slot];
+        memcpy(r.v0, v, 12); memcpy(r.v1, v + 3, 12); memcpy(r.v2, v + 6, 12);
+        r.tri_id = (int32_t)id;
+        r.material = s->material_id[id];
+        r.sign = s->tangent_sign[id];
+        ErTriAttr& a = attr[slot];
+        memcpy(a.n, &s->normals[(size_t)id * 9], 36);
+        memcpy(a.t, &s->tangents[(size_t)id * 9], 36);
+        memcpy(a.uv, &s->uvs[(size_t)id * 6], 24);
+        a.pad[0] = a.pad[1] = a.pad[2] = a.pad[3] = 0;
+    }
+    hipEvent_t u0, u1;
+    HIP_TRY(hipEventCreate(&u0));
+    HIP_TRY(hipEventCreate(&u1));
+    HIP_TRY(hipEventRecord(u0, s->stream));
+    int rc;
+    if ((rc = upload(s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * 4, s->stream)) != ER_OK) return rc;
+    if ((rc = upload(s->d_isect, isect.data(), n * 3, s->stream)) != ER_OK) return rc;
+    if ((rc = upload(s->d_attr, attr.data(), n * 7, s->stream)) != ER_OK) return rc;
+    if ((rc = upload(s->d_materials, s->materials.data(), s->materials.size(), s->stream)) != ER_OK) return rc;
+
+    // textures: one float pool + a table
+    std::vector<DevTex> table(s->textures.size());
+    std::vector<float> pool;
+    for (size_t i = 0; i < s->textures.size(); i++) {
+        const HostTex& t = s->textures[i];
+        table[i] = DevTex{t.width, t.height, t.channels, t.filter, (uint32_t)pool.size()};
+        pool.insert(pool.end(), t.data.begin(), t.data.end());
+    }
+    DevTex hd{s->hdri_tex.width, s->hdri_tex.height, s->hdri_tex.channels, s->hdri_tex.filter, (uint32_t)pool.size()};
+    pool.insert(pool.end(), s->hdri_tex.data.begin(), s->hdri_tex.data.end());
+    if (pool.size() >= (1ull << 32)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: texture pool exceeds 2^32 floats");
+    if ((rc = upload(s->d_textures, table.data(), table.size(), s->stream)) != ER_OK) return rc;
+    if ((rc = upload(s->d_tex_pool, pool.data(), pool.size(), s->stream)) != ER_OK) return rc;
+    if ((rc = upload(s->d_cdf, s->hdri_cdf.data(), s->hdri_cdf.size(), s->stream)) != ER_OK) return rc;
+
+    size_t npx = (size_t)s->x_res * s->y_res;
+    if ((rc = upload(s->d_passes, nullptr, npx * ER_PASS_COUNT, s->stream)) != ER_OK) return rc;
+    if ((rc = upload(s->d_samples, nullptr, npx, s->stream)) != ER_OK) return rc;
+    if ((rc = upload(s->d_rng, nullptr, npx, s->stream)) != ER_OK) return rc;
+    std::vector<uint32_t> owned = s->tiles_of(s->params.rank, world);
+    if ((rc = upload(s->d_owned, owned.data(), owned.size(), s->stream)) != ER_OK) return rc;
+    if ((rc = upload(s->d_counters, nullptr, 1, s->stream)) != ER_OK) return rc;
+    HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, sizeof(DevCounters), s->stream));
+    HIP_TRY(hipEventRecord(u1, s->stream));
+
+    float scene_scale = 0;
+    for (int a = 0; a < 3; a++) scene_scale = std::max(scene_scale, std::max(std::fabs(bvh.lo[a]), std::fabs(bvh.hi[a])));
+    scene_scale = std::max(scene_scale, std::max(std::fabs(s->camera.position.x), std::max(std::fabs(s->camera.position.y), std::fabs(s->camera.position.z))));
+
+    DevScene& D = s->dev;
+    memset(&D, 0, sizeof(D));
+    D.nodes = s->d_nodes.p;
+    D.tri_isect = s->d_isect.p;
+    D.tri_attr = s->d_attr.p;
+    D.tri_count = s->tri_count;
+    D.node_count = (uint32_t)bvh.nodes.size();
+    D.prune_margin = bvh.lift_bound + 1e-5f * scene_scale;
+    D.materials = s->d_materials.p;
+    D.textures = s->d_textures.p;
+    D.tex_pool = s->d_tex_pool.p;
+    D.hdri_tex = hd;
+    D.hdri_cdf = s->d_cdf.p;
+    D.hdri_radiance_sum = s->hdri_radiance_sum;
+    D.cam = s->camera;
+    D.x_res = s->x_res;
+    D.y_res = s->y_res;
+    D.tiles_x = (s->x_res + ER_TILE - 1) / ER_TILE;
+    D.tiles_y = (s->y_res + ER_TILE - 1) / ER_TILE;
+    D.max_bounces = s->params.max_bounces;
+    D.passes = s->d_passes.p;
+    D.samples = s->d_samples.p;
+    D.rng = s->d_rng.p;
+    D.owned_tiles = s->d_owned.p;
+    D.owned_tile_count = (uint32_t)owned.size();
+    D.counters = s->d_counters.p;
+
+    er_launch_setup(D, s->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    float up_ms = 0;
+    (void)hipEventElapsedTime(&up_ms, u0, u1);
+    (void)hipEventDestroy(u0);
+    (void)hipEventDestroy(u1);
+
+    s->accel.node_count = (uint32_t)bvh.nodes.size();
+    s->accel.node_bytes = sizeof(ErNode);
+    s->accel.leaf_count = bvh.leaf_count;
+    s->accel.max_depth = bvh.max_depth;
+    s->accel.tri_record_bytes = sizeof(ErTriIsect);
+    s->accel.build_ms = (float)bvh.build_ms;
+    s->accel.upload_ms = up_ms;
+    s->accel.lift_bound = bvh.lift_bound;
+    s->begun = true;
+    return ER_OK;
+}
+
+int er_render_samples_async(ErScene* s, uint32_t n) {
+    if (!s) return fail(ER_ERR_INVALID_ARG, "er_render_samples: NULL scene");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if (!s->begun) return fail(ER_ERR_STATE, "er_render_samples: er_render_begin has not succeeded");
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->timing_open) {
+        HIP_TRY(hipEventRecord(s->ev_start, s->stream));
+        s->timing_open = true;
+    }
+    er_launch_render(s->dev, n, (s->params.flags & ER_FLAG_COUNTERS) != 0, s->stream);
+    HIP_TRY(hipGetLastError());
+    return ER_OK;
+}
+
+int er_wait(ErScene* s, float* elapsed_ms) {
+    if (!s) return fail(ER_ERR_INVALID_ARG, "er_wait: NULL scene");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if (!s->begun) return fail(ER_ERR_STATE, "er_wait: er_render_begin has not succeeded");
+    HIP_TRY(hipSetDevice(s->device));
+    float ms = 0;
+    if (s->timing_open) {
+        HIP_TRY(hipEventRecord(s->ev_stop, s->stream));
+        HIP_TRY(hipEventSynchronize(s->ev_stop));
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_start, s->ev_stop));
+        s->timing_open = false;
+    } else {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+    }
+    if (elapsed_ms) *elapsed_ms = ms;
+    return ER_OK;
+}
+
+int er_render_samples(ErScene* s, uint32_t n) {
+    int rc = er_render_samples_async(s, n);
+    if (rc != ER_OK) return rc;
+    return er_wait(s, nullptr);
+}
+
+static int read_back(ErScene* s, const void* src, void* dst, size_t bytes, const char* who) {
+    if (!s || !dst) return fail(ER_ERR_INVALID_ARG, std::string(who) + ": NULL argument");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if (!s->begun) return fail(ER_ERR_STATE, std::string(who) + ": er_render_begin has not succeeded");
+    HIP_TRY(hipSetDevice(s->device));
+    // ordered after everything enqueued so far: a sample-boundary snapshot, never a torn read
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return ER_OK;
+}
+
+int er_samples_done(ErScene* s, uint32_t* out) {
+    if (!s) return fail(ER_ERR_INVALID_ARG, "er_samples_done: NULL scene");
+    // dev_samples[0], reference src/Managers.cpp:217-221; with tile sharding pixel 0 may belong to another
+    // rank, so report the first owned pixel instead.
+    uint32_t first = 0;
+    if (s->begun && s->params.world > 1) {
+        std::vector<uint32_t> t = s->tiles_of(s->params.rank, s->params.world);
+        if (!t.empty()) {
+            uint32_t tiles_x = (s->x_res + ER_TILE - 1) / ER_TILE;
+            first = (t[0] / tiles_x) * ER_TILE * s->x_res + (t[0] % tiles_x) * ER_TILE;
+        }
+    }
+    return read_back(s, s->d_samples.p + first, out, sizeof(uint32_t), "er_samples_done");
+}
+
+int er_read_pass(ErScene* s, int pass, float* dst) {
+    if (pass < 0 || pass >= ER_PASS_COUNT) return fail(ER_ERR_INVALID_ARG, "er_read_pass: pass out of range");
+    if (!s) return fail(ER_ERR_INVALID_ARG, "er_read_pass: NULL scene");
+    size_t npx = (size_t)s->x_res * s->y_res;
+    return read_back(s, s->d_passes.p + (size_t)pass * npx, dst, npx * sizeof(float4), "er_read_pass");
+}
+int er_read_samples(ErScene* s, uint32_t* dst) {
+    if (!s) return fail(ER_ERR_INVALID_ARG, "er_read_samples: NULL scene");
+    return read_back(s, s->d_samples.p, dst, (size_t)s->x_res * s->y_res * 4, "er_read_samples");
+}
+int er_read_rng(ErScene* s, uint32_t* dst) {
+    if (!s) return fail(ER_ERR_INVALID_ARG, "er_read_rng: NULL scene");
+    return read_back(s, s->d_rng.p, dst, (size_t)s->x_res * s->y_res * 4, "er_read_rng");
+}
+
+int er_owned_count(ErScene* s, uint32_t rank, uint64_t* out) {
+    if (!s || !out) return fail(ER_ERR_INVALID_ARG, "er_owned_count: NULL argument");
+    uint32_t world = s->begun ? s->params.world : 1;
+    if (rank >= world) return fail(ER_ERR_INVALID_ARG, "er_owned_count: rank >= world");
+    *out = (uint64_t)s->tiles_of(rank, world).size() * 64;
+    return ER_OK;
+}
+
+int er_pack_owned(ErScene* s, int pass, void* dev_dst) {
+    if (!s || !dev_dst) return fail(ER_ERR_INVALID_ARG, "er_pack_owned: NULL argument");
+    if (pass < 0 || pass >= ER_PASS_COUNT) return fail(ER_ERR_INVALID_ARG, "er_pack_owned: pass out of range");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if (!s->begun) return fail(ER_ERR_STATE, "er_pack_owned: er_render_begin has not succeeded");
+    HIP_TRY(hipSetDevice(s->device));
+    er_launch_pack(s->dev, s->d_owned.p, s->dev.owned_tile_count, pass, dev_dst, s->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return ER_OK;
+}
+
+int er_unpack_owned(ErScene* s, int pass, uint32_t src_rank, const void* dev_src) {
+    if (!s || !dev_src) return fail(ER_ERR_INVALID_ARG, "er_unpack_owned: NULL argument");
+    if (pass < 0 || pass >= ER_PASS_COUNT) return fail(ER_ERR_INVALID_ARG, "er_unpack_owned: pass out of range");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if (!s->begun) return fail(ER_ERR_STATE, "er_unpack_owned: er_render_begin has not succeeded");
+    if (src_rank >= s->params.world) return fail(ER_ERR_INVALID_ARG, "er_unpack_owned: src_rank >= world");
+    HIP_TRY(hipSetDevice(s->device));
+    auto it = s->d_rank_tiles.find(src_rank);
+    if (it == s->d_rank_tiles.end()) {
+        std::vector<uint32_t> t = s->tiles_of(src_rank, s->params.world);
+        DevBuf<uint32_t> b;
+        int rc = upload(b, t.data(), t.size(), s->stream);
+        if (rc != ER_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(s->stream));   // t goes out of scope
+        it = s->d_rank_tiles.emplace(src_rank, b).first;
+    }
+    er_launch_unpack(s->dev, it->second.p, (uint32_t)it->second.n, pass, dev_src, s->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return ER_OK;
+}
+
+int er_get_counters(ErScene* s, ErCounters* out) {
+    if (!s || !out) return fail(ER_ERR_INVALID_ARG, "er_get_counters: NULL argument");
+    DevCounters c;
+    int rc = read_back(s, s->d_counters.p, &c, sizeof(c), "er_get_counters");
+    if (rc != ER_OK) return rc;
+    out->paths = c.paths; out->bounce_samples = c.bounce_samples; out->rays = c.rays; out->node_visits = c.node_visits;
+    out->tri_tests = c.tri_tests; out->shaded_hits = c.shaded_hits; out->texel_fetches = c.texel_fetches;
+    out->hdri_samples = c.hdri_samples;
+    return ER_OK;
+}
+
+int er_accel_info(ErScene* s, ErAccelInfo* out) {
+    if (!s || !out) return fail(ER_ERR_INVALID_ARG, "er_accel_info: NULL argument");
+    if (!s->begun) return fail(ER_ERR_STATE, "er_accel_info: er_render_begin has not succeeded");
+    *out = s->accel;
+    return ER_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,11 @@
+// er_kernels.h -- host-callable launch wrappers of the gfx950 kernels (er_kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+struct DevScene;
+
+void er_launch_setup(const DevScene& S, hipStream_t stream);
+void er_launch_render(const DevScene& S, uint32_t n_samples, bool count, hipStream_t stream);
+void er_launch_pack(const DevScene& S, const uint32_t* tiles, uint32_t ntiles, int pass, void* dst, hipStream_t stream);
+void er_launch_unpack(const DevScene& S, const uint32_t* tiles, uint32_t ntiles, int pass, const void* src, hipStream_t stream);

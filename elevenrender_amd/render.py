@@ -1,0 +1,147 @@
+"""Python host mirror of the reference's device-boundary objects, on top of the C ABI.
+
+Mirrors (names and call semantics) the part of the reference host API that drives the
+hot path -- RenderParameters (reference src/kernel.h:51-69) and RenderingManager
+(src/Managers.h:41-66: start_rendering / get_pass / get_render_info) -- so that a driver
+written against the reference reads the same.  The production host is C++
+(elevenrender_amd/host/); this mirror exists for tests, bench.py and scripting.  It never
+computes anything itself: every call goes through libeleven_hip.so and fails loudly if
+that library or a HIP device is missing.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import abi
+
+
+@dataclass
+class RenderParameters:
+    """reference RenderParameters (width/height/sampleTarget/denoise/device/block_size) plus
+    the two knobs the MI355X build adds with reference defaults (max_bounces 5, one GPU)."""
+    width: int = 1280
+    height: int = 720
+    sampleTarget: int = 100
+    denoise: bool = False
+    device: str = ""          # "name|platform" (src/Managers.cpp:201) or "" / "hip:N" for ordinal N
+    block_size: int = 8
+    max_bounces: int = 5
+    rank: int = 0
+    world: int = 1
+    flags: int = 0
+
+
+@dataclass
+class RenderInfo:
+    samples: int = 0
+
+
+def list_devices():
+    """get_sycl_info equivalent (src/CommandManager.cpp:303-362): one dict per HIP device."""
+    lib = abi.load()
+    out = []
+    for i in range(lib.er_device_count()):
+        info = abi.ErDeviceInfo()
+        abi.check(lib.er_device_info(i, C.byref(info)))
+        out.append({"name": info.name.decode(), "platform": info.platform.decode(),
+                    "memory": int(info.memory_bytes), "max_compute_units": int(info.compute_units),
+                    "is_compatible": bool(info.compatible), "online_compiler": False, "type": "gpu",
+                    "arch": info.arch.decode()})
+    return out
+
+
+class RenderingManager:
+    """start_rendering(scene) / render(n) / get_pass(name) / get_render_info() over the C ABI."""
+
+    def __init__(self, pars: RenderParameters = None):
+        self.pars = pars or RenderParameters()
+        self.lib = abi.load()
+        self.handle = C.c_void_p()
+        self.scene = None
+
+    # -- reference: RenderingManager::start_rendering(Scene*) (src/Managers.cpp:234-275).  The
+    #    reference also spawns the render thread here; callers of this mirror call render().
+    def start_rendering(self, scene: abi.SceneData):
+        self.close()
+        self.scene = scene
+        self.pars.width, self.pars.height = scene.x_res, scene.y_res
+        abi.check(self.lib.er_scene_create(C.byref(scene.desc()), C.byref(self.handle)))
+        dev = 0
+        sel = self.pars.device
+        if sel.startswith("hip:"):
+            dev = int(sel[4:])
+        elif sel:
+            dev = self.lib.er_device_find(sel.encode())
+            if dev < 0:
+                abi.check(dev)
+        p = abi.ErRenderParams(self.pars.sampleTarget, self.pars.block_size, self.pars.max_bounces, dev,
+                               self.pars.rank, self.pars.world, self.pars.flags)
+        abi.check(self.lib.er_render_begin(self.handle, C.byref(p)))
+
+    # -- reference: kernel_render_enqueue's sample loop (src/kernel.cpp:689-700)
+    def render(self, n_samples, blocking=True):
+        if blocking:
+            abi.check(self.lib.er_render_samples(self.handle, n_samples))
+        else:
+            abi.check(self.lib.er_render_samples_async(self.handle, n_samples))
+
+    def wait(self):
+        ms = C.c_float()
+        abi.check(self.lib.er_wait(self.handle, C.byref(ms)))
+        return ms.value
+
+    # -- reference: RenderingManager::get_pass(std::string) (src/Managers.cpp:287-302, parsePass kernel.cpp:50-73)
+    def get_pass(self, name="beauty"):
+        p = abi.PASS_NAMES.get(str(name).lower(), abi.PASS_BEAUTY)   # unknown names -> BEAUTY, as parsePass
+        out = np.empty((self.scene.y_res, self.scene.x_res, 4), np.float32)
+        abi.check(self.lib.er_read_pass(self.handle, p, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    # -- reference: RenderingManager::get_render_info (src/Managers.cpp:211-232)
+    def get_render_info(self):
+        v = C.c_uint32()
+        abi.check(self.lib.er_samples_done(self.handle, C.byref(v)))
+        return RenderInfo(samples=v.value)
+
+    def read_samples(self):
+        out = np.empty(self.scene.x_res * self.scene.y_res, np.uint32)
+        abi.check(self.lib.er_read_samples(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def read_rng(self):
+        out = np.empty(self.scene.x_res * self.scene.y_res, np.uint32)
+        abi.check(self.lib.er_read_rng(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
+    def counters(self):
+        c = abi.ErCounters()
+        abi.check(self.lib.er_get_counters(self.handle, C.byref(c)))
+        return {n: int(getattr(c, n)) for n, _ in abi.ErCounters._fields_}
+
+    def accel_info(self):
+        a = abi.ErAccelInfo()
+        abi.check(self.lib.er_accel_info(self.handle, C.byref(a)))
+        return {n: getattr(a, n) for n, _ in abi.ErAccelInfo._fields_}
+
+    def owned_count(self, rank):
+        v = C.c_uint64()
+        abi.check(self.lib.er_owned_count(self.handle, rank, C.byref(v)))
+        return int(v.value)
+
+    def pack_owned(self, pass_id, dev_ptr):
+        abi.check(self.lib.er_pack_owned(self.handle, pass_id, C.c_void_p(dev_ptr)))
+
+    def unpack_owned(self, pass_id, src_rank, dev_ptr):
+        abi.check(self.lib.er_unpack_owned(self.handle, pass_id, src_rank, C.c_void_p(dev_ptr)))
+
+    def close(self):
+        if self.handle:
+            self.lib.er_scene_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,204 @@
+/* eleven_hip.h -- C ABI of the MI355X path-tracing core (libeleven_hip.so).
+ *
+ * This is the drop-in boundary for ElevenRender's per-sample hot path.  It replaces
+ * the SYCL seam of the reference between RenderingManager and the device runtime:
+ *
+ *   reference interface (file:line under the reference tree)        replaced by
+ *   --------------------------------------------------------------  ----------------------
+ *   dev_Scene::dev_Scene(Scene*)            src/kernel.cpp:244-266   er_scene_create
+ *   copy_scene(dev_Scene*,dev_Scene*,queue) src/SYCLCopy.cpp:3-104   er_scene_create + er_render_begin
+ *   renderSetup(q,scene,dev,spp,bs)         src/kernel.cpp:651-678   er_render_begin
+ *   kernel_render_enqueue(q,spp,bs,...)     src/kernel.cpp:680-706   er_render_samples
+ *   renderingKernel(dev_Scene*,idx,samples) src/kernel.cpp:477-646   (the HIP kernels behind er_render_samples)
+ *   RenderingManager::get_pass(string)      src/Managers.cpp:287-302 er_read_pass
+ *   RenderingManager::get_render_info()     src/Managers.cpp:211-232 er_samples_done
+ *   is_compatible(sycl::device&)            src/kernel.cpp:708-720   er_device_info().compatible
+ *   get_sycl_info device enumeration        src/CommandManager.cpp:303-362  er_device_count / er_device_info
+ *   NameSelector "name|platform"            src/Managers.cpp:191-208 er_device_find
+ *
+ * Conventions: plain C, PODs and raw pointers only; every entry point returns
+ * ER_OK (0) or a negative ErStatus and never throws; er_last_error() gives the
+ * text for the calling thread.  All host pointers in ErSceneDesc stay owned by the
+ * caller and are copied during er_scene_create.  The library fails loudly
+ * (ER_ERR_NO_DEVICE) when no gfx950 device / HIP runtime is usable: there is no
+ * CPU fallback behind this ABI.
+ */
+#ifndef ELEVEN_HIP_H
+#define ELEVEN_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ER_ABI_VERSION 1
+
+typedef enum ErStatus {
+    ER_OK = 0,
+    ER_ERR_INVALID_ARG = -1,
+    ER_ERR_NO_DEVICE = -2,
+    ER_ERR_HIP = -3,
+    ER_ERR_STATE = -4,     /* call order violated (e.g. render before begin) */
+    ER_ERR_OOM = -5
+} ErStatus;
+
+/* Pass planes, reference enum Passes (src/kernel.h:8). DENOISE is allocated and
+ * initialised like the others but never written by the kernel (src/kernel.cpp:604). */
+typedef enum ErPass { ER_PASS_BEAUTY = 0, ER_PASS_DENOISE = 1, ER_PASS_NORMAL = 2,
+                      ER_PASS_TANGENT = 3, ER_PASS_BITANGENT = 4, ER_PASS_COUNT = 5 } ErPass;
+
+typedef struct ErVec3 { float x, y, z; } ErVec3;
+
+/* reference Camera (src/Camera.h:5-25); rotation in degrees, XYZ Euler. */
+typedef struct ErCamera {
+    float focal_length, sensor_width, sensor_height, aperture, focus_distance;
+    ErVec3 rotation;
+    int32_t bokeh;
+    ErVec3 position;
+} ErCamera;
+
+/* reference Material without its strings (src/Material.h:20-47). Texture ids < 0 = constant. */
+typedef struct ErMaterial {
+    int32_t albedo_tex, emission_tex, roughness_tex, metallic_tex, normal_tex, opacity_tex,
+            transmission_tex;
+    int32_t albedo_shader_id;          /* -1 = none; see asl_shade, src/shader.cpp:6-10 */
+    ErVec3 albedo, emission;
+    float opacity, roughness, metallic, clearcoat_gloss, clearcoat, anisotropic, eta,
+          transmission, specular, specular_tint, sheen_tint, subsurface, sheen, ax, ay;
+} ErMaterial;
+
+/* reference Texture (src/Texture.h:12-73): interleaved f32, row-major, `channels` per texel.
+ * filter: 0 = NO_FILTER, 1 = BILINEAR. */
+typedef struct ErTexture {
+    int32_t width, height, channels, filter;
+    const float* data;
+} ErTexture;
+
+/* reference HDRI (src/HDRI.h:9-42). cdf has width*height+1 entries; if NULL the library
+ * builds it exactly as HDRI::generateCDF does (src/HDRI.cpp:62-83) and radiance_sum is ignored. */
+typedef struct ErHdri {
+    ErTexture texture;
+    const float* cdf;
+    float radiance_sum;
+} ErHdri;
+
+/* reference PointLight (src/PointLight.h:4-16). The reference never evaluates point
+ * lights (src/kernel.cpp:269-301 has no caller); they are used only when
+ * ErRenderParams.flags has ER_FLAG_POINT_LIGHTS (a build-defined extension). */
+typedef struct ErPointLight { ErVec3 position, radiance; } ErPointLight;
+
+/* Flattened reference Scene (src/Scene.h:24-73, Tri src/Tri.h:8-21). Triangle arrays are
+ * indexed [tri][corner][component]. */
+typedef struct ErSceneDesc {
+    uint32_t tri_count;
+    const float* vertices;       /* [tri_count][3][3] */
+    const float* normals;        /* [tri_count][3][3] */
+    const float* tangents;       /* [tri_count][3][3] */
+    const float* uvs;            /* [tri_count][3][2] */
+    const float* tangent_sign;   /* [tri_count] */
+    const int32_t* material_id;  /* [tri_count] */
+    uint32_t material_count;
+    const ErMaterial* materials;
+    uint32_t texture_count;
+    const ErTexture* textures;
+    ErHdri hdri;
+    ErCamera camera;
+    uint32_t point_light_count;
+    const ErPointLight* point_lights;
+    uint32_t x_res, y_res;
+} ErSceneDesc;
+
+#define ER_FLAG_POINT_LIGHTS 1u   /* extension, default off = reference behaviour */
+#define ER_FLAG_COUNTERS     2u   /* count node visits / triangle tests (slower kernel variant) */
+
+/* reference RenderParameters (src/kernel.h:51-69) + what the MI355X build adds. */
+typedef struct ErRenderParams {
+    uint32_t sample_target;   /* informational, as in the reference */
+    uint32_t block_size;      /* accepted for protocol compatibility; launch geometry is ours */
+    uint32_t max_bounces;     /* 0 -> 5, the literal of src/kernel.cpp:508 */
+    int32_t device;           /* HIP device ordinal */
+    uint32_t rank, world;     /* pixel-tile shard: this process renders tiles t with t % world == rank; world 0 -> 1 */
+    uint32_t flags;
+} ErRenderParams;
+
+typedef struct ErDeviceInfo {
+    char name[256];
+    char platform[64];        /* "AMD HIP" */
+    uint64_t memory_bytes;
+    uint32_t compute_units;
+    int32_t compatible;       /* 1 iff gcnArchName starts with gfx950 */
+    char arch[64];
+} ErDeviceInfo;
+
+/* Counters of the work done since er_render_begin (all ranks count only their own pixels). */
+typedef struct ErCounters {
+    uint64_t paths;            /* pixel-samples finished */
+    uint64_t bounce_samples;   /* executed iterations of the bounce loop = the Msamples metric unit */
+    uint64_t rays;             /* closest-hit + shadow traversals started */
+    uint64_t node_visits;      /* only with ER_FLAG_COUNTERS */
+    uint64_t tri_tests;        /* only with ER_FLAG_COUNTERS */
+    uint64_t shaded_hits;      /* closest hits shaded */
+    uint64_t texel_fetches;    /* only with ER_FLAG_COUNTERS */
+    uint64_t hdri_samples;     /* CDF searches */
+} ErCounters;
+
+typedef struct ErScene ErScene;   /* opaque */
+
+int er_abi_version(void);
+const char* er_last_error(void);
+
+int er_device_count(void);
+int er_device_info(int index, ErDeviceInfo* out);
+/* index of the device whose "name|platform" equals selector, or a negative status. */
+int er_device_find(const char* selector);
+
+int er_scene_create(const ErSceneDesc* desc, ErScene** out);
+void er_scene_destroy(ErScene* scene);
+
+/* Builds the acceleration structure, uploads, initialises passes/samples/RNG (setupKernel,
+ * src/kernel.cpp:176-213, for EVERY pixel). May be called again to restart a render. */
+int er_render_begin(ErScene* scene, const ErRenderParams* params);
+
+/* Adds n samples to every owned pixel. Blocking. Equivalent to n launches of renderingKernel. */
+int er_render_samples(ErScene* scene, uint32_t n);
+/* Non-blocking form + explicit wait; elapsed_ms (may be NULL) = device time of everything
+ * enqueued since the previous er_wait, measured with HIP events on the library's stream. */
+int er_render_samples_async(ErScene* scene, uint32_t n);
+int er_wait(ErScene* scene, float* elapsed_ms);
+
+/* reference get_render_info semantic: dev_samples[0], i.e. samples added + 1. */
+int er_samples_done(ErScene* scene, uint32_t* out);
+
+/* Copies one pass plane (x_res*y_res*4 floats, RGBA, row-major, idx = y*x_res + x) to host memory.
+ * With world > 1 only owned pixels are valid; others are left at the setup value (0,0,0,1). */
+int er_read_pass(ErScene* scene, int pass, float* dst_rgba);
+int er_read_samples(ErScene* scene, uint32_t* dst);     /* x_res*y_res */
+int er_read_rng(ErScene* scene, uint32_t* dst);         /* x_res*y_res */
+
+/* Multi-GPU framebuffer combine helpers (the collective itself is done by the host with
+ * RCCL; these move owned pixels between the full plane and a compact device buffer).
+ * er_owned_count: number of pixels this rank owns.
+ * er_pack_owned: dev_dst[owned][4] <- owned pixels of `pass`, in owned-pixel order (device pointer).
+ * er_unpack_owned: scatters a compact buffer of rank `src_rank` into this scene's full plane. */
+int er_owned_count(ErScene* scene, uint32_t rank, uint64_t* out);
+int er_pack_owned(ErScene* scene, int pass, void* dev_dst);
+int er_unpack_owned(ErScene* scene, int pass, uint32_t src_rank, const void* dev_src);
+
+int er_get_counters(ErScene* scene, ErCounters* out);
+
+/* Description of the built acceleration structure, for roofline accounting. */
+typedef struct ErAccelInfo {
+    uint32_t node_count, node_bytes;   /* wide nodes */
+    uint32_t leaf_count, max_depth;
+    uint32_t tri_record_bytes;         /* bytes fetched per triangle test */
+    float build_ms, upload_ms;
+    float lift_bound;                  /* global bound on |shadingPosition - geomPosition| */
+} ErAccelInfo;
+int er_accel_info(ErScene* scene, ErAccelInfo* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELEVEN_HIP_H */

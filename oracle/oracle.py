@@ -1,0 +1,157 @@
+"""ctypes binding of the CPU oracle (oracle/liberoracle.so).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by the product package.  PARITY UNPINNED, see er_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(_HERE))
+from elevenrender_amd import abi  # noqa: E402  (struct layouts of include/eleven_hip.h only)
+
+LIB_PATH = os.path.join(_HERE, "liberoracle.so")
+
+
+class OracleOpts(C.Structure):
+    _fields_ = [("math_mode", C.c_int32), ("max_bounces", C.c_int32), ("traversal", C.c_int32), ("threads", C.c_int32)]
+
+
+class OracleCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("paths", "bounce_samples", "rays", "node_visits", "tri_tests", "tri_hits",
+                                          "shaded_hits", "texel_fetches", "hdri_samples")]
+
+
+class OracleTraceRec(C.Structure):
+    _fields_ = [("bounce", C.c_int32), ("tri", C.c_int32), ("shadow_tri", C.c_int32), ("opaque", C.c_int32),
+                ("position", C.c_float * 3), ("wi", C.c_float * 3), ("light", C.c_float * 3), ("reduction", C.c_float * 3)]
+
+
+MATH_LIBM, MATH_ER = 0, 1
+TRAV_REFERENCE_BVH, TRAV_BRUTE = 0, 1
+
+_lib = None
+_FP = C.POINTER(C.c_float)
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "liberoracle.so"] + (["-B"] if force else []))
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(LIB_PATH)
+    L.oracle_create.restype = C.c_void_p
+    L.oracle_create.argtypes = [C.POINTER(abi.ErSceneDesc), C.POINTER(OracleOpts)]
+    L.oracle_destroy.argtypes = [C.c_void_p]
+    L.oracle_build_seconds.restype = C.c_double
+    L.oracle_build_seconds.argtypes = [C.c_void_p]
+    L.oracle_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.oracle_read_pass.argtypes = [C.c_void_p, C.c_int, _FP]
+    L.oracle_read_samples.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.oracle_read_rng.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    L.oracle_counters.argtypes = [C.c_void_p, C.POINTER(OracleCounters)]
+    L.oracle_trace_pixel.restype = C.c_int
+    L.oracle_trace_pixel.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(OracleTraceRec), C.c_int]
+    L.oracle_closest_hit.argtypes = [C.c_void_p, _FP, _FP, C.c_int, C.POINTER(C.c_int32), _FP]
+    L.oracle_jenkins_oaat_u32.restype = C.c_uint32
+    L.oracle_jenkins_oaat_u32.argtypes = [C.c_uint32]
+    L.oracle_jenkins_oaat_bytes.restype = C.c_uint32
+    L.oracle_jenkins_oaat_bytes.argtypes = [C.c_char_p, C.c_size_t]
+    L.oracle_rng_stream.argtypes = [C.c_uint32, C.c_int, C.POINTER(C.c_uint32), _FP]
+    L.oracle_xorshift32.argtypes = [C.POINTER(C.c_uint32)]
+    L.oracle_camera_ray.argtypes = [C.POINTER(abi.ErCamera), C.c_uint32, C.c_uint32, C.c_int, C.c_int, _FP, C.c_int, _FP, _FP]
+    L.oracle_tri_hit.restype = C.c_int
+    L.oracle_tri_hit.argtypes = [_FP, _FP, _FP, _FP, C.c_float, _FP, _FP, _FP]
+    L.oracle_box_hit.restype = C.c_int
+    L.oracle_box_hit.argtypes = [_FP, _FP, _FP, _FP]
+    L.oracle_disney_eval.argtypes = [_FP, _FP, _FP, _FP, C.c_int, _FP]
+    L.oracle_disney_pdf.restype = C.c_float
+    L.oracle_disney_pdf.argtypes = [_FP, _FP, _FP, _FP, C.c_int]
+    L.oracle_disney_sample.argtypes = [_FP, _FP, _FP, C.c_float, C.c_float, C.c_float, C.c_int, _FP]
+    L.oracle_spherical_mapping.argtypes = [_FP, C.c_int, _FP, _FP]
+    L.oracle_reverse_spherical_mapping.argtypes = [C.c_float, C.c_float, C.c_int, _FP]
+    L.oracle_texture_fetch.argtypes = [C.POINTER(abi.ErTexture), C.c_float, C.c_float, C.c_int, _FP]
+    L.oracle_hdri_cdf.argtypes = [C.POINTER(abi.ErTexture), _FP, _FP]
+    L.oracle_hdri_binary_search.restype = C.c_int
+    L.oracle_hdri_binary_search.argtypes = [_FP, C.c_float, C.c_int]
+    L.oracle_hdri_pdf.restype = C.c_float
+    L.oracle_hdri_pdf.argtypes = [C.POINTER(abi.ErTexture), C.c_float, C.c_int, C.c_int, C.c_int]
+    L.oracle_math.argtypes = [C.c_int, C.c_int, _FP, _FP, _FP, C.c_int]
+    _lib = L
+    return L
+
+
+def fp(a):
+    return a.ctypes.data_as(_FP)
+
+
+class Oracle:
+    """One oracle render state for a abi.SceneData."""
+
+    def __init__(self, scene, math_mode=MATH_ER, max_bounces=5, traversal=TRAV_REFERENCE_BVH, threads=1):
+        self.scene = scene
+        self.L = lib()
+        opts = OracleOpts(math_mode, max_bounces, traversal, threads)
+        self.h = self.L.oracle_create(C.byref(scene.desc()), C.byref(opts))
+        self.npx = scene.x_res * scene.y_res
+
+    def close(self):
+        if self.h:
+            self.L.oracle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def build_seconds(self):
+        return self.L.oracle_build_seconds(self.h)
+
+    def render(self, n_samples, idx0=0, idx1=0):
+        self.L.oracle_render(self.h, n_samples, idx0, idx1)
+
+    def read_pass(self, p):
+        out = np.empty((self.scene.y_res, self.scene.x_res, 4), np.float32)
+        self.L.oracle_read_pass(self.h, p, fp(out))
+        return out
+
+    def read_samples(self):
+        out = np.empty(self.npx, np.uint32)
+        self.L.oracle_read_samples(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return out
+
+    def read_rng(self):
+        out = np.empty(self.npx, np.uint32)
+        self.L.oracle_read_rng(self.h, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+        return out
+
+    def counters(self):
+        c = OracleCounters()
+        self.L.oracle_counters(self.h, C.byref(c))
+        return {n: getattr(c, n) for n, _ in OracleCounters._fields_}
+
+    def trace_pixel(self, idx, max_recs=64):
+        recs = (OracleTraceRec * max_recs)()
+        n = self.L.oracle_trace_pixel(self.h, idx, recs, max_recs)
+        return [recs[i] for i in range(n)]
+
+    def closest_hit(self, origins, dirs):
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        n = len(o)
+        tri = np.empty(n, np.int32)
+        pos = np.empty((n, 3), np.float32)
+        self.L.oracle_closest_hit(self.h, fp(o), fp(d), n, tri.ctypes.data_as(C.POINTER(C.c_int32)), fp(pos))
+        return tri, pos
