@@ -553,3 +553,81 @@ int er_accel_info(ErScene* s, ErAccelInfo* out) {
 }
 
 }  // extern "C"
+
+// ---- host-only debug hook (include/eleven_hip_debug.h) ----
+#include "../../include/eleven_hip_debug.h"
+
+extern "C" int er_debug_bvh_check(const float* vertices, const float* normals, uint32_t tri_count, int threads, ErBvhCheck* out) {
+    if (!out || (tri_count && (!vertices || !normals))) return fail(ER_ERR_INVALID_ARG, "er_debug_bvh_check: NULL argument");
+    ErBvhBuild b;
+    er_build_bvh(vertices, normals, tri_count, threads, &b);
+    memset(out, 0, sizeof(*out));
+    out->node_count = (uint32_t)b.nodes.size();
+    out->leaf_count = b.leaf_count;
+    out->max_depth = b.max_depth;
+    out->lift_bound = b.lift_bound;
+    out->build_ms = (float)b.build_ms;
+    std::vector<uint8_t> seen(tri_count, 0), visited(b.nodes.size(), 0);
+    struct Item { int32_t ref; float lo[3], hi[3]; bool has_box; };
+    std::vector<Item> stack;
+    if (!b.nodes.empty()) stack.push_back(Item{0, {0, 0, 0}, {0, 0, 0}, false});
+    auto area = [](const float* lo, const float* hi) {
+        float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+        return 2.0 * ((double)x * y + (double)x * z + (double)y * z);
+    };
+    double root_area = 0;
+    if (!b.nodes.empty()) {
+        const ErNode& r = b.nodes[0];
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; a++) {
+            lo[a] = r.c1 == ER_BVH_NO_CHILD ? r.lo0[a] : std::min(r.lo0[a], r.lo1[a]);
+            hi[a] = r.c1 == ER_BVH_NO_CHILD ? r.hi0[a] : std::max(r.hi0[a], r.hi1[a]);
+        }
+        root_area = area(lo, hi);
+    }
+    while (!stack.empty()) {
+        Item it = stack.back();
+        stack.pop_back();
+        if (it.ref == ER_BVH_NO_CHILD) continue;
+        if (it.ref >= 0) {
+            if ((size_t)it.ref >= b.nodes.size()) { out->uncontained++; continue; }
+            if (visited[it.ref]++) { out->duplicate_tris++; continue; }
+            const ErNode& n = b.nodes[it.ref];
+            const float* los[2] = {n.lo0, n.lo1};
+            const float* his[2] = {n.hi0, n.hi1};
+            const int32_t cs[2] = {n.c0, n.c1};
+            for (int k = 0; k < 2; k++) {
+                if (cs[k] == ER_BVH_NO_CHILD) continue;
+                if (it.has_box)
+                    for (int a = 0; a < 3; a++)
+                        if (los[k][a] < it.lo[a] || his[k][a] > it.hi[a]) out->uncontained++;
+                Item c;
+                c.ref = cs[k];
+                c.has_box = true;
+                memcpy(c.lo, los[k], 12);
+                memcpy(c.hi, his[k], 12);
+                uint32_t cnt = 0;
+                if (cs[k] < 0) cnt = ((uint32_t)~cs[k] & 7u) + 1;
+                if (root_area > 0) out->sah_cost += area(los[k], his[k]) / root_area * (cs[k] < 0 ? cnt : 1.0);
+                stack.push_back(c);
+            }
+        } else {
+            uint32_t v = (uint32_t)~it.ref, first = v >> 3, cnt = (v & 7u) + 1;
+            out->max_leaf_size = std::max(out->max_leaf_size, cnt);
+            for (uint32_t i = 0; i < cnt; i++) {
+                uint32_t slot = first + i;
+                if (slot >= tri_count) { out->uncontained++; continue; }
+                uint32_t id = b.slot_to_tri[slot];
+                if (seen[id]++) out->duplicate_tris++;
+                out->tris_in_leaves++;
+                for (int k = 0; k < 3; k++)
+                    for (int a = 0; a < 3; a++) {
+                        float p = vertices[(size_t)id * 9 + k * 3 + a];
+                        if (p < it.lo[a] || p > it.hi[a]) out->uncontained++;
+                    }
+            }
+        }
+    }
+    for (uint8_t v : visited) if (!v) out->unreachable_nodes++;
+    return ER_OK;
+}

@@ -15,7 +15,7 @@ class Rand:
     """splitmix64 evaluated at counters seed*2^32+stream.. : u01(n) -> float32 in [0,1)."""
 
     def __init__(self, seed, stream=0):
-        self.base = (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(stream) * np.uint64(0xD1B54A32D192ED03)) & _M64
+        self.base = np.uint64((int(seed) * 0x9E3779B97F4A7C15 + int(stream) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF)
         self.ctr = np.uint64(0)
 
     def u64(self, n):

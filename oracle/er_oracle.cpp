@@ -898,8 +898,11 @@ void oracle_render(Oracle* o, uint32_t n_samples, uint32_t idx0, uint32_t idx1) 
     auto work = [&](int tid) {
         uint32_t span = idx1 - idx0;
         uint32_t a = idx0 + (uint32_t)((uint64_t)span * tid / nt), b = idx0 + (uint32_t)((uint64_t)span * (tid + 1) / nt);
+        OracleCounters local;   // thread-private (adjacent vector slots would false-share)
+        memset(&local, 0, sizeof(local));
         for (uint32_t s = 0; s < n_samples; s++)
-            for (uint32_t idx = a; idx < b; idx++) o->renderingKernel(idx, ctrs[tid], nullptr, 0, nullptr);
+            for (uint32_t idx = a; idx < b; idx++) o->renderingKernel(idx, local, nullptr, 0, nullptr);
+        ctrs[tid] = local;
     };
     if (nt == 1) work(0);
     else {

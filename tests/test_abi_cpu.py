@@ -1,0 +1,140 @@
+"""The C-ABI library on a machine without a GPU: it loads, exports every declared symbol,
+validates arguments, refuses to compute (no CPU fallback), and its host-side BVH builder is sound."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from elevenrender_amd import abi, render, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(er_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = abi.load()
+    names = declared_symbols("eleven_hip.h")
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/eleven_hip.h but not exported"
+        assert n in abi.SYMBOLS, f"{n} has no ctypes prototype in abi.py"
+    for n in declared_symbols("eleven_hip_debug.h"):
+        assert hasattr(lib, n)
+    assert lib.er_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    # sizes the C compiler gives the PODs (checked against a tiny C program's output at build time would be
+    # circular; these are the natural-alignment sizes of the declared fields)
+    assert C.sizeof(abi.ErVec3) == 12
+    assert C.sizeof(abi.ErCamera) == 5 * 4 + 12 + 4 + 12
+    assert C.sizeof(abi.ErMaterial) == 8 * 4 + 24 + 15 * 4
+    assert C.sizeof(abi.ErTexture) == 24
+    assert C.sizeof(abi.ErCounters) == 64
+    assert C.sizeof(abi.ErRenderParams) == 28
+
+
+def test_argument_validation_and_error_text():
+    lib = abi.load()
+    h = C.c_void_p()
+    assert lib.er_scene_create(None, C.byref(h)) == abi.ER_ERR_INVALID_ARG
+    assert b"NULL" in lib.er_last_error()
+    sc = scenes.cornell(16, 16)
+    d = sc.desc()
+    d.x_res = 0
+    assert lib.er_scene_create(C.byref(d), C.byref(h)) == abi.ER_ERR_INVALID_ARG
+    d.x_res = 16
+    sc.material_id[3] = 99
+    assert lib.er_scene_create(C.byref(d), C.byref(h)) == abi.ER_ERR_INVALID_ARG
+    assert b"material_id" in lib.er_last_error()
+    sc.material_id[3] = 0
+    assert lib.er_scene_create(C.byref(d), C.byref(h)) == abi.ER_OK
+    # calls before er_render_begin are state errors, never crashes
+    buf = np.zeros(16 * 16 * 4, np.float32)
+    assert lib.er_render_samples(h, 1) == abi.ER_ERR_STATE
+    assert lib.er_read_pass(h, 0, buf.ctypes.data_as(C.POINTER(C.c_float))) == abi.ER_ERR_STATE
+    assert lib.er_read_pass(h, 7, buf.ctypes.data_as(C.POINTER(C.c_float))) == abi.ER_ERR_INVALID_ARG
+    p = abi.ErRenderParams(16, 8, 5, 0, 3, 2, 0)          # rank >= world
+    assert lib.er_render_begin(h, C.byref(p)) == abi.ER_ERR_INVALID_ARG
+    lib.er_scene_destroy(h)
+    lib.er_scene_destroy(None)
+
+
+def test_no_cpu_fallback_without_a_device():
+    lib = abi.load()
+    if lib.er_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    rm = render.RenderingManager()
+    with pytest.raises(abi.ErError) as e:
+        rm.start_rendering(scenes.cornell(16, 16))
+    assert e.value.code == abi.ER_ERR_NO_DEVICE
+    assert render.list_devices() == []
+
+
+class ErBvhCheck(C.Structure):
+    _fields_ = [("node_count", C.c_uint32), ("leaf_count", C.c_uint32), ("max_depth", C.c_uint32),
+                ("max_leaf_size", C.c_uint32), ("tris_in_leaves", C.c_uint32), ("duplicate_tris", C.c_uint32),
+                ("uncontained", C.c_uint32), ("unreachable_nodes", C.c_uint32), ("lift_bound", C.c_float),
+                ("build_ms", C.c_float), ("sah_cost", C.c_double)]
+
+
+def bvh_check(verts, normals, threads=0):
+    lib = abi.load()
+    lib.er_debug_bvh_check.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_int, C.POINTER(ErBvhCheck)]
+    out = ErBvhCheck()
+    v = np.ascontiguousarray(verts, np.float32)
+    n = np.ascontiguousarray(normals, np.float32)
+    P = C.POINTER(C.c_float)
+    assert lib.er_debug_bvh_check(v.ctypes.data_as(P), n.ctypes.data_as(P), len(v), threads, C.byref(out)) == 0
+    return out
+
+
+@pytest.mark.parametrize("n_tris", [0, 1, 3, 4, 5, 12, 1000, 100000])
+def test_bvh_builder_invariants(n_tris):
+    if n_tris == 12:
+        sc = scenes.cornell(8, 8)
+        v, nn = sc.vertices, sc.normals
+    else:
+        v = scenes.soup_geometry(n_tris, seed=n_tris + 1)
+        nn, _ = scenes.face_frame(v) if n_tris else (np.zeros((0, 3, 3), np.float32), None)
+    c = bvh_check(v, nn)
+    assert c.tris_in_leaves == n_tris and c.duplicate_tris == 0 and c.uncontained == 0 and c.unreachable_nodes == 0
+    assert c.max_leaf_size <= 4 and c.max_depth <= 32
+    if n_tris > 4:
+        assert c.node_count == c.leaf_count - 1
+    if n_tris >= 1000:
+        assert c.lift_bound < 1e-4          # flat-shaded soup: shading position == geometric position up to rounding
+
+
+def test_bvh_builder_degenerate_inputs_stay_bounded():
+    # all triangles identical (every centroid coincides): SAH cannot split, median fallback must
+    n = 5000
+    one = np.array([[0, 0, 3], [1, 0, 3], [0, 1, 3]], np.float32)
+    v = np.repeat(one[None], n, axis=0)
+    nn, _ = scenes.face_frame(v)
+    c = bvh_check(v, nn)
+    assert c.tris_in_leaves == n and c.duplicate_tris == 0 and c.max_depth <= 32
+    # a long thin line of triangles (worst case for unbalanced SAH splits)
+    x = np.cumsum(np.geomspace(1e-6, 1.0, n)).astype(np.float32)
+    v = one[None] * 1e-3 + np.stack([x, np.zeros(n, np.float32), np.zeros(n, np.float32)], -1)[:, None, :]
+    c = bvh_check(v.astype(np.float32), nn)
+    assert c.tris_in_leaves == n and c.max_depth <= 32 and c.uncontained == 0
+    # smooth normals: the lift bound is positive and bounded by the triangle size
+    sc = scenes.blob_instances(n_instances=2, tris_per_blob=200, x_res=8, y_res=8)
+    c = bvh_check(sc.vertices, sc.normals)
+    assert 0 < c.lift_bound < 0.05 and c.uncontained == 0
+
+
+def test_bvh_builder_threaded_equals_serial():
+    v = scenes.soup_geometry(60000, seed=5)
+    nn, _ = scenes.face_frame(v)
+    a, b = bvh_check(v, nn, threads=1), bvh_check(v, nn, threads=8)
+    assert (a.node_count, a.leaf_count, a.max_depth) == (b.node_count, b.leaf_count, b.max_depth)
+    assert abs(a.sah_cost - b.sah_cost) < 1e-9 * max(1.0, a.sah_cost)
