@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -17,6 +18,7 @@
 #include "er_bvh.h"
 #include "er_device.h"
 #include "er_kernels.h"
+#include "er_wavefront.h"
 
 namespace {
 
@@ -115,12 +117,18 @@ struct ErScene {
     bool timing_open = false;
     DevScene dev{};
     ErAccelInfo accel{};
-    DevBuf<float4> d_nodes, d_isect, d_attr, d_passes;
+    DevBuf<float4> d_nodes, d_nodes8, d_isect, d_attr, d_passes;
     DevBuf<ErMaterial> d_materials;
     DevBuf<DevTex> d_textures;
     DevBuf<float> d_tex_pool, d_cdf;
     DevBuf<uint32_t> d_samples, d_rng, d_owned;
     DevBuf<DevCounters> d_counters;
+    DevBuf<float4> d_wf4;        // 11 float4 arrays of the wavefront state, back to back
+    DevBuf<uint32_t> d_wf1;      // hit, left, occluded, 4 queues, counts
+    DevBuf<uint2> d_spill;
+    DevBuf<uint32_t> d_guide;
+    WfState wf{};
+    uint32_t trace_blocks = 0, shade_blocks = 0;
     std::map<uint32_t, DevBuf<uint32_t>> d_rank_tiles;   // tile lists of other ranks (for unpack)
     std::mutex mtx;
 
@@ -133,9 +141,9 @@ struct ErScene {
         return t;
     }
     void release_device() {
-        d_nodes.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_materials.release();
+        d_nodes.release(); d_nodes8.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_materials.release();
         d_textures.release(); d_tex_pool.release(); d_cdf.release(); d_samples.release(); d_rng.release();
-        d_owned.release(); d_counters.release();
+        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release();
         for (auto& kv : d_rank_tiles) kv.second.release();
         d_rank_tiles.clear();
         if (ev_start) (void)hipEventDestroy(ev_start);
@@ -149,6 +157,20 @@ struct ErScene {
 };
 
 namespace {
+
+// guide table of er_cdf.h: guide[j] = first i in [0,length] with cdf[i] >= j/buckets
+int er_build_cdf_guide(const float* cdf, int length, std::vector<uint32_t>& guide) {
+    int buckets = 1;
+    while (buckets < length / 8 && buckets < (1 << 22)) buckets <<= 1;
+    guide.assign((size_t)buckets + 1, (uint32_t)length);
+    int i = 0;
+    for (int j = 0; j <= buckets; j++) {
+        float thr = (float)j / (float)buckets;
+        while (i < length && cdf[i] < thr) i++;
+        guide[j] = (uint32_t)i;
+    }
+    return buckets;
+}
 
 template <class T>
 int upload(DevBuf<T>& b, const void* src, size_t count, hipStream_t s) {
@@ -311,7 +333,7 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     er_build_bvh(s->vertices.data(), s->normals.data(), s->tri_count, 0, &bvh);
     if (bvh.max_depth > ER_BVH_MAX_DEPTH) return fail(ER_ERR_STATE, "er_render_begin: BVH deeper than the traversal stack");
     size_t n = s->tri_count;
-    std::vector<ErTriIsect> isect(n);
+    std::vector<ErTriIsect> isect(n + 1);      // +1: the wide traversal fetches triangles in pairs
     std::vector<ErTriAttr> attr(n);
     for (size_t slot = 0; slot < n; slot++) {
         uint32_t id = bvh.slot_to_tri[slot];
@@ -319,13 +341,14 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
         ErTriIsect& r = isect[slot];
         memcpy(r.v0, v, 12); memcpy(r.v1, v + 3, 12); memcpy(r.v2, v + 6, 12);
         r.tri_id = (int32_t)id;
-        r.material = s->material_id[id];
+        r.lift = bvh.tri_lift[id];
         r.sign = s->tangent_sign[id];
         ErTriAttr& a = attr[slot];
         memcpy(a.n, &s->normals[(size_t)id * 9], 36);
         memcpy(a.t, &s->tangents[(size_t)id * 9], 36);
         memcpy(a.uv, &s->uvs[(size_t)id * 6], 24);
-        a.pad[0] = a.pad[1] = a.pad[2] = a.pad[3] = 0;
+        a.material = s->material_id[id];
+        a.pad[0] = a.pad[1] = a.pad[2] = 0;
     }
     hipEvent_t u0, u1;
     HIP_TRY(hipEventCreate(&u0));
@@ -333,7 +356,12 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     HIP_TRY(hipEventRecord(u0, s->stream));
     int rc;
     if ((rc = upload(s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * 4, s->stream)) != ER_OK) return rc;
-    if ((rc = upload(s->d_isect, isect.data(), n * 3, s->stream)) != ER_OK) return rc;
+    memset(&isect[n], 0, sizeof(ErTriIsect));
+    if ((rc = upload(s->d_isect, isect.data(), (n + 1) * 3, s->stream)) != ER_OK) return rc;
+    std::vector<float4> n8((bvh.nodes8.size() * 5) + 1, make_float4(0, 0, 0, 0));   // +16 B: the unified fetch reads 96 B
+    if (!bvh.nodes8.empty()) memcpy(n8.data(), bvh.nodes8.data(), bvh.nodes8.size() * sizeof(ErNode8));
+    if ((rc = upload(s->d_nodes8, n8.data(), n8.size(), s->stream)) != ER_OK) return rc;
+    if (bvh.max_depth8 > ER_BVH_MAX_DEPTH) return fail(ER_ERR_STATE, "er_render_begin: wide BVH deeper than the traversal stack");
     if ((rc = upload(s->d_attr, attr.data(), n * 7, s->stream)) != ER_OK) return rc;
     if ((rc = upload(s->d_materials, s->materials.data(), s->materials.size(), s->stream)) != ER_OK) return rc;
 
@@ -351,6 +379,9 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     if ((rc = upload(s->d_textures, table.data(), table.size(), s->stream)) != ER_OK) return rc;
     if ((rc = upload(s->d_tex_pool, pool.data(), pool.size(), s->stream)) != ER_OK) return rc;
     if ((rc = upload(s->d_cdf, s->hdri_cdf.data(), s->hdri_cdf.size(), s->stream)) != ER_OK) return rc;
+    std::vector<uint32_t> guide;
+    int buckets = er_build_cdf_guide(s->hdri_cdf.data(), s->hdri_tex.width * s->hdri_tex.height, guide);
+    if ((rc = upload(s->d_guide, guide.data(), guide.size(), s->stream)) != ER_OK) return rc;
 
     size_t npx = (size_t)s->x_res * s->y_res;
     if ((rc = upload(s->d_passes, nullptr, npx * ER_PASS_COUNT, s->stream)) != ER_OK) return rc;
@@ -360,6 +391,31 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     if ((rc = upload(s->d_owned, owned.data(), owned.size(), s->stream)) != ER_OK) return rc;
     if ((rc = upload(s->d_counters, nullptr, 1, s->stream)) != ER_OK) return rc;
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, sizeof(DevCounters), s->stream));
+    if (!(p->flags & ER_FLAG_MEGAKERNEL)) {
+        // wavefront path state: one slot per owned pixel lane
+        size_t slots = owned.size() * 64;
+        if ((rc = upload(s->d_wf4, nullptr, slots * 11, s->stream)) != ER_OK) return rc;
+        if ((rc = upload(s->d_wf1, nullptr, slots * 10 + WF_COUNTS, s->stream)) != ER_OK) return rc;
+        WfState& W = s->wf;
+        float4* f = s->d_wf4.p;
+        W.ray_o = f; W.ray_d = f + slots; W.light = f + 2 * slots; W.reduc = f + 3 * slots;
+        W.aov_n = f + 4 * slots; W.aov_t = f + 5 * slots; W.aov_b = f + 6 * slots;
+        W.sh_o = f + 7 * slots; W.sh_d = f + 8 * slots; W.c_vis = f + 9 * slots; W.c_occ = f + 10 * slots;
+        uint32_t* u = s->d_wf1.p;
+        W.hit = (int*)u; W.left = u + slots; W.occluded = (int*)(u + 2 * slots);
+        W.q[0] = u + 3 * slots; W.q[1] = u + 4 * slots; W.qs[0] = u + 5 * slots; W.qs[1] = u + 6 * slots;
+        W.hit2 = (int*)(u + 7 * slots); W.occ_a = (int*)(u + 8 * slots); W.occ_b = (int*)(u + 9 * slots);
+        W.counts = u + 10 * slots;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+        uint32_t cus = (uint32_t)prop.multiProcessorCount;
+        s->trace_blocks = cus * 20;   // persistent waves; LDS (8 KB/wave) admits 20 per CU
+        s->shade_blocks = cus * 8;
+        if (const char* e = getenv("ER_TRACE_WAVES_PER_CU")) s->trace_blocks = cus * (uint32_t)std::max(1, atoi(e));   // tuning knob
+        if (const char* e = getenv("ER_SHADE_WAVES_PER_CU")) s->shade_blocks = cus * (uint32_t)std::max(1, atoi(e));
+        if ((rc = upload(s->d_spill, nullptr, (size_t)s->trace_blocks * ER_BVH_MAX_DEPTH * 64, s->stream)) != ER_OK) return rc;
+        W.spill = s->d_spill.p;
+    }
     HIP_TRY(hipEventRecord(u1, s->stream));
 
     float scene_scale = 0;
@@ -369,16 +425,21 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     DevScene& D = s->dev;
     memset(&D, 0, sizeof(D));
     D.nodes = s->d_nodes.p;
+    D.nodes8 = s->d_nodes8.p;
     D.tri_isect = s->d_isect.p;
     D.tri_attr = s->d_attr.p;
     D.tri_count = s->tri_count;
     D.node_count = (uint32_t)bvh.nodes.size();
     D.prune_margin = bvh.lift_bound + 1e-5f * scene_scale;
+    D.max_lift = bvh.lift_bound;
+    D.scene_scale = scene_scale;
     D.materials = s->d_materials.p;
     D.textures = s->d_textures.p;
     D.tex_pool = s->d_tex_pool.p;
     D.hdri_tex = hd;
     D.hdri_cdf = s->d_cdf.p;
+    D.hdri_guide = s->d_guide.p;
+    D.hdri_buckets = buckets;
     D.hdri_radiance_sum = s->hdri_radiance_sum;
     D.cam = s->camera;
     D.x_res = s->x_res;
@@ -422,7 +483,16 @@ int er_render_samples_async(ErScene* s, uint32_t n) {
         HIP_TRY(hipEventRecord(s->ev_start, s->stream));
         s->timing_open = true;
     }
-    er_launch_render(s->dev, n, (s->params.flags & ER_FLAG_COUNTERS) != 0, s->stream);
+    const bool count = (s->params.flags & ER_FLAG_COUNTERS) != 0;
+    if (s->params.flags & ER_FLAG_MEGAKERNEL) {
+        er_launch_render(s->dev, n, count, s->stream);
+    } else if (n > 0) {
+        // a path takes at most max_bounces ray steps plus one finalize-only step
+        const uint32_t iters = n * (s->params.max_bounces + 1);
+        er_launch_wf_begin(s->dev, s->wf, n, s->stream);
+        for (uint32_t it = 0; it < iters; it++)
+            er_launch_wf_iteration(s->dev, s->wf, it & 1, count, s->trace_blocks, s->shade_blocks, s->stream);
+    }
     HIP_TRY(hipGetLastError());
     return ER_OK;
 }
@@ -556,6 +626,14 @@ int er_accel_info(ErScene* s, ErAccelInfo* out) {
 
 // ---- host-only debug hook (include/eleven_hip_debug.h) ----
 #include "../../include/eleven_hip_debug.h"
+
+extern "C" int er_debug_cdf_search(const float* cdf, int length, const float* values, int32_t* out, int count) {
+    if (!cdf || !values || !out || length <= 0) return fail(ER_ERR_INVALID_ARG, "er_debug_cdf_search: bad argument");
+    std::vector<uint32_t> guide;
+    int buckets = er_build_cdf_guide(cdf, length, guide);
+    for (int i = 0; i < count; i++) out[i] = er_cdf_search(cdf, length, guide.data(), buckets, values[i]);
+    return ER_OK;
+}
 
 extern "C" int er_debug_bvh_check(const float* vertices, const float* normals, uint32_t tri_count, int threads, ErBvhCheck* out) {
     if (!out || (tri_count && (!vertices || !normals))) return fail(ER_ERR_INVALID_ARG, "er_debug_bvh_check: NULL argument");

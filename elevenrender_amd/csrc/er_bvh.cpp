@@ -155,6 +155,122 @@ struct Builder {
 
 }  // namespace
 
+// ---- collapse the binary tree into the 8-wide compressed tree (see ErNode8) ----
+static void collapse_bvh8(ErBvhBuild* out) {
+    out->nodes8.clear();
+    out->max_depth8 = 0;
+    if (out->nodes.empty()) return;
+    std::vector<ErNode>& N2 = out->nodes;
+    const uint32_t tri_count = (uint32_t)out->slot_to_tri.size();
+    std::vector<uint32_t> new_order;          // new slot -> old slot
+    new_order.reserve(tri_count);
+    struct Child { int32_t ref; float lo[3], hi[3]; int32_t parent2; int which; };
+    struct Work { uint32_t n8; int32_t n2; uint32_t depth; };
+    std::vector<Work> queue;
+    out->nodes8.emplace_back();
+    queue.push_back(Work{0, 0, 1});
+    auto box_area = [](const Child& c) {
+        float x = c.hi[0] - c.lo[0], y = c.hi[1] - c.lo[1], z = c.hi[2] - c.lo[2];
+        return 2.0f * (x * y + x * z + y * z);
+    };
+    auto add_children = [&](std::vector<Child>& ch, int32_t n2) {
+        const ErNode& nd = N2[n2];
+        if (nd.c0 != ER_BVH_NO_CHILD) { Child c; c.ref = nd.c0; memcpy(c.lo, nd.lo0, 12); memcpy(c.hi, nd.hi0, 12); c.parent2 = n2; c.which = 0; ch.push_back(c); }
+        if (nd.c1 != ER_BVH_NO_CHILD) { Child c; c.ref = nd.c1; memcpy(c.lo, nd.lo1, 12); memcpy(c.hi, nd.hi1, 12); c.parent2 = n2; c.which = 1; ch.push_back(c); }
+    };
+    for (size_t qi = 0; qi < queue.size(); qi++) {
+        Work w = queue[qi];
+        out->max_depth8 = std::max(out->max_depth8, w.depth);
+        std::vector<Child> ch;
+        add_children(ch, w.n2);
+        while (ch.size() < 8) {   // open the inner child with the largest surface area
+            int best = -1;
+            float ba = -1;
+            for (size_t i = 0; i < ch.size(); i++)
+                if (ch[i].ref >= 0) { float a = box_area(ch[i]); if (a > ba) { ba = a; best = (int)i; } }
+            if (best < 0) break;
+            int32_t n2 = ch[best].ref;
+            ch.erase(ch.begin() + best);
+            add_children(ch, n2);
+        }
+        // node bounds
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (const Child& c : ch) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], c.lo[a]); hi[a] = std::max(hi[a], c.hi[a]); }
+        // slot assignment: greedy on score = (centroid - centre) . (+-1,+-1,+-1)
+        int slot_of[8], child_in[8];
+        for (int i = 0; i < 8; i++) { slot_of[i] = -1; child_in[i] = -1; }
+        struct Score { float v; int c, s; };
+        std::vector<Score> sc;
+        for (size_t i = 0; i < ch.size(); i++)
+            for (int s8 = 0; s8 < 8; s8++) {
+                float v = 0;
+                for (int a = 0; a < 3; a++) {
+                    float rel = 0.5f * (ch[i].lo[a] + ch[i].hi[a]) - 0.5f * (lo[a] + hi[a]);
+                    v += ((s8 >> a) & 1) ? rel : -rel;
+                }
+                sc.push_back(Score{v, (int)i, s8});
+            }
+        std::stable_sort(sc.begin(), sc.end(), [](const Score& a, const Score& b) { return a.v > b.v; });
+        for (const Score& x : sc)
+            if (slot_of[x.c] < 0 && child_in[x.s] < 0) { slot_of[x.c] = x.s; child_in[x.s] = x.c; }
+        // fill the node
+        ErNode8 nd;
+        memset(&nd, 0, sizeof(nd));
+        float scale[3];
+        for (int a = 0; a < 3; a++) {
+            nd.p[a] = lo[a];
+            float ext = hi[a] - lo[a];
+            int e = 0;
+            if (ext > 0) { (void)std::frexp(ext / 255.0f, &e); }   // 2^e > ext/255
+            else e = -126;
+            if (e < -126) e = -126;
+            // make sure 255 steps of 2^e reach hi in float arithmetic
+            while (lo[a] + 255.0f * std::ldexp(1.0f, e) < hi[a]) e++;
+            nd.e[a] = (uint8_t)(e + 127);
+            scale[a] = std::ldexp(1.0f, e);
+        }
+        nd.child_base = (uint32_t)out->nodes8.size();
+        nd.tri_base = (uint32_t)new_order.size();
+        uint32_t tri_off = 0;
+        for (int s8 = 0; s8 < 8; s8++) {
+            int ci = child_in[s8];
+            if (ci < 0) continue;
+            const Child& c = ch[ci];
+            for (int a = 0; a < 3; a++) {
+                float fl = std::floor((c.lo[a] - nd.p[a]) / scale[a]);
+                float fh = std::ceil((c.hi[a] - nd.p[a]) / scale[a]);
+                int ql = (int)std::min(255.0f, std::max(0.0f, fl));
+                int qh = (int)std::min(255.0f, std::max(0.0f, fh));
+                // conservative in exactly the arithmetic the kernel decodes with: p + q * scale (one rounding)
+                while (ql > 0 && nd.p[a] + (float)ql * scale[a] > c.lo[a]) ql--;
+                while (qh < 255 && nd.p[a] + (float)qh * scale[a] < c.hi[a]) qh++;
+                nd.qlo[a][s8] = (uint8_t)ql;
+                nd.qhi[a][s8] = (uint8_t)qh;
+            }
+            if (c.ref >= 0) {
+                nd.imask |= (uint8_t)(1u << s8);
+                nd.meta[s8] = 1;
+                uint32_t idx = (uint32_t)out->nodes8.size();
+                out->nodes8.emplace_back();
+                queue.push_back(Work{idx, c.ref, w.depth + 1});
+            } else {
+                uint32_t v = (uint32_t)~c.ref, first = v >> 3, count = (v & 7u) + 1u;
+                nd.meta[s8] = (uint8_t)((count << 5) | tri_off);
+                uint32_t new_first = (uint32_t)new_order.size();
+                for (uint32_t i = 0; i < count; i++) new_order.push_back(first + i);
+                tri_off += count;
+                // keep the binary tree valid over the new triangle order
+                int32_t nref = ~(int32_t)((new_first << 3) | (count - 1));
+                if (c.which == 0) N2[c.parent2].c0 = nref; else N2[c.parent2].c1 = nref;
+            }
+        }
+        out->nodes8[w.n8] = nd;
+    }
+    std::vector<uint32_t> s2t(tri_count);
+    for (uint32_t i = 0; i < tri_count; i++) s2t[i] = out->slot_to_tri[new_order[i]];
+    out->slot_to_tri.swap(s2t);
+}
+
 void er_build_bvh(const float* vertices, const float* normals, uint32_t tri_count, int threads, ErBvhBuild* out) {
     auto t0 = std::chrono::steady_clock::now();
     if (threads <= 0) threads = (int)std::max(1u, std::thread::hardware_concurrency());
@@ -165,6 +281,7 @@ void er_build_bvh(const float* vertices, const float* normals, uint32_t tri_coun
     out->lift_bound = 0;
     Builder B;
     B.prims.resize(tri_count);
+    out->tri_lift.assign(tri_count, 0.0f);
     Box sb;
     sb.reset();
     double lift = 0;
@@ -188,6 +305,7 @@ void er_build_bvh(const float* vertices, const float* normals, uint32_t tri_coun
         // bound on |shadingPosition - geomPosition| (src/Tri.h:106-112): the hit point is a convex
         // combination of the vertices and each p_j moves it by |dot(P - v_j, n_j)| * |n_j|
         const float* nn = normals + (size_t)i * 9;
+        double tl = 0;
         for (int j = 0; j < 3; j++) {
             double nx = nn[3 * j], ny = nn[3 * j + 1], nz = nn[3 * j + 2];
             double nl = std::sqrt(nx * nx + ny * ny + nz * nz);
@@ -195,9 +313,11 @@ void er_build_bvh(const float* vertices, const float* normals, uint32_t tri_coun
                 if (k == j) continue;
                 double dx = (double)v[3 * k] - v[3 * j], dy = (double)v[3 * k + 1] - v[3 * j + 1], dz = (double)v[3 * k + 2] - v[3 * j + 2];
                 double l = std::fabs(dx * nx + dy * ny + dz * nz) * nl;
-                if (l > lift) lift = l;
+                if (l > tl) tl = l;
             }
         }
+        if (tl > lift) lift = tl;
+        out->tri_lift[i] = (float)(tl * 1.01) + 1e-30f;
     }
     for (int a = 0; a < 3; a++) { out->lo[a] = tri_count ? sb.lo[a] : 0; out->hi[a] = tri_count ? sb.hi[a] : 0; }
     out->lift_bound = (float)(lift * 1.01);
@@ -263,5 +383,6 @@ void er_build_bvh(const float* vertices, const float* normals, uint32_t tri_coun
     }
     out->slot_to_tri.resize(tri_count);
     for (uint32_t i = 0; i < tri_count; i++) out->slot_to_tri[i] = B.prims[i].id;
+    collapse_bvh8(out);
     out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }

@@ -30,7 +30,7 @@ static_assert(sizeof(ErNode) == 64, "node must be 64 bytes");
 
 struct ErTriIsect {         // 48 bytes: what a triangle test reads
     float v0[3]; int32_t tri_id;
-    float v1[3]; int32_t material;
+    float v1[3]; float lift;     // bound on |shadingPosition - geomPosition| for this triangle (src/Tri.h:106-117)
     float v2[3]; float sign;
 };
 static_assert(sizeof(ErTriIsect) == 48, "isect record must be 48 bytes");
@@ -39,17 +39,38 @@ struct ErTriAttr {          // 112 bytes: read for candidates (normals) and for 
     float n[3][3];          // 36
     float t[3][3];          // 36
     float uv[3][2];         // 24
-    float pad[4];           // -> 112
+    int32_t material;       // 4
+    float pad[3];           // -> 112
 };
 static_assert(sizeof(ErTriAttr) == 112, "attr record must be 112 bytes");
 
+// 8-wide compressed node (layout after Ylitie, Karras, Laine 2017, "Efficient incoherent ray traversal on
+// GPUs through compressed wide BVHs"): child boxes are 8-bit offsets from `p` in units of 2^e per axis,
+// quantised OUTWARD (decoded box always contains the float box), inner children are consecutive nodes from
+// child_base, leaf children's triangles are consecutive slots from tri_base.  Children sit in slots whose
+// 3-bit index encodes their position relative to the node centre, so `slot ^ octant` orders a ray's visits.
+struct ErNode8 {            // 80 bytes = five 16-byte loads
+    float p[3];
+    uint8_t e[3];           // biased exponents: scale = 2^(e - 127) as an IEEE bit pattern (e << 23)
+    uint8_t imask;          // bit s: slot s holds an inner node
+    uint32_t child_base;
+    uint32_t tri_base;
+    uint8_t meta[8];        // 0 = empty; inner: 1; leaf: (count << 5) | offset   (count 1..4, offset < 32)
+    uint8_t qlo[3][8];
+    uint8_t qhi[3][8];
+};
+static_assert(sizeof(ErNode8) == 80, "wide node must be 80 bytes");
+
 struct ErBvhBuild {
+    std::vector<ErNode8> nodes8;         // 8-wide compressed tree over the same triangle order
+    uint32_t max_depth8 = 0;
     std::vector<ErNode> nodes;
     std::vector<uint32_t> slot_to_tri;   // leaf order -> original triangle id
     uint32_t leaf_count = 0;
     uint32_t max_depth = 0;
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};   // scene bounds
     float lift_bound = 0;                // max over tris of the bound on |shadingPosition - geomPosition|
+    std::vector<float> tri_lift;         // the same bound per ORIGINAL triangle id
     double build_ms = 0;
 };
 

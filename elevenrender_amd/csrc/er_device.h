@@ -11,6 +11,7 @@
 
 #include "../../include/eleven_hip.h"
 #include "er_bvh.h"
+#include "er_cdf.h"
 #include "er_math.h"
 
 #define ER_TILE 8                 // 8x8 pixel tile = one 64-lane wavefront
@@ -27,17 +28,21 @@ struct DevCounters {
 
 struct DevScene {
     // acceleration structure + geometry (leaf order)
-    const float4* nodes;        // 4 x float4 per node
+    const float4* nodes;        // 4 x float4 per node (binary tree: megakernel + exact re-trace)
+    const float4* nodes8;       // 5 x float4 per node (8-wide compressed tree: er_wf_trace)
     const float4* tri_isect;    // 3 x float4 per slot
     const float4* tri_attr;     // 7 x float4 per slot
     uint32_t tri_count, node_count;
-    float prune_margin;         // lift bound + rounding slack, see trace_closest
+    float prune_margin;         // lift bound + rounding slack, see trace()
+    float max_lift, scene_scale; // inputs of the interval bookkeeping in er_wf_trace
     // shading
     const ErMaterial* materials;
     const DevTex* textures;
     const float* tex_pool;
     DevTex hdri_tex;
     const float* hdri_cdf;
+    const uint32_t* hdri_guide;  // er_cdf.h
+    int32_t hdri_buckets;
     float hdri_radiance_sum;
     ErCamera cam;
     uint32_t x_res, y_res, tiles_x, tiles_y;
@@ -226,7 +231,7 @@ ERD void full_hit(const DevScene& S, uint32_t slot, const Ray& ray, HitFull& h) 
     float u = 0, v = 0, t = 0;
     tri_mt(v0, v1, v2, ray, u, v, t);
     const float4* p = S.tri_attr + (size_t)slot * 7;
-    float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5];
+    float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6];
     F3 n0 = f3(q0.x, q0.y, q0.z), n1 = f3(q0.w, q1.x, q1.y), n2 = f3(q1.z, q1.w, q2.x);
     F3 t0 = f3(q2.y, q2.z, q2.w), t1 = f3(q3.x, q3.y, q3.z), t2 = f3(q3.w, q4.x, q4.y);
     float uv0x = q4.z, uv0y = q4.w, uv1x = q5.x, uv1y = q5.y, uv2x = q5.z, uv2y = q5.w;
@@ -241,7 +246,7 @@ ERD void full_hit(const DevScene& S, uint32_t slot, const Ray& ray, HitFull& h) 
     h.gnormal = compNormal;
     h.tangent = t0 + (t1 - t0) * u + (t2 - t0) * v;
     h.bitangent = __builtin_bit_cast(float, c.w) * cross(h.normal, h.tangent);
-    h.material = __builtin_bit_cast(int, b.w);
+    h.material = __builtin_bit_cast(int, q6.x);
 }
 
 // ---- box test, src/BVH.cpp:27-61 (formula kept; dirfrac hoisted out of the loop) ----

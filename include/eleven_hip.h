@@ -112,6 +112,7 @@ typedef struct ErSceneDesc {
 
 #define ER_FLAG_POINT_LIGHTS 1u   /* extension, default off = reference behaviour */
 #define ER_FLAG_COUNTERS     2u   /* count node visits / triangle tests (slower kernel variant) */
+#define ER_FLAG_MEGAKERNEL   4u   /* one fused kernel per call instead of the wavefront schedule (same results) */
 
 /* reference RenderParameters (src/kernel.h:51-69) + what the MI355X build adds. */
 typedef struct ErRenderParams {

@@ -23,6 +23,10 @@ typedef struct ErBvhCheck {
 /* Builds the BVH for [tri_count][3][3] vertices/normals exactly as er_render_begin does and checks its invariants. */
 int er_debug_bvh_check(const float* vertices, const float* normals, uint32_t tri_count, int threads, ErBvhCheck* out);
 
+/* Runs the library's HDRI CDF search (elevenrender_amd/csrc/er_cdf.h, the replacement of the 21-level
+ * HDRI::binarySearch, reference src/HDRI.cpp:85-98) on the host for `count` values. */
+int er_debug_cdf_search(const float* cdf, int length, const float* values, int32_t* out, int count);
+
 #ifdef __cplusplus
 }
 #endif

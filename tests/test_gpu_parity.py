@@ -115,3 +115,15 @@ def test_gpu_reproduces_golden_fixtures(name):
         assert same.mean() >= 0.999, (p, same.mean())
     assert (g["rng"] == z["rng"]).mean() >= 0.999 and (g["samples"] == z["samples"]).mean() >= 0.999
     assert g["counters"]["bounce_samples"] == int(z["counters"][1])
+
+
+def test_megakernel_schedule_equals_wavefront_schedule():
+    """ER_FLAG_MEGAKERNEL (one fused kernel) and the default wavefront schedule are the same arithmetic."""
+    sc = scenes.soup(3000, 96, 64, seed=11, hdri_size=(64, 32))
+    a = gpu_render(sc, 5, max_bounces=8)
+    b = gpu_render(sc, 5, max_bounces=8, flags=abi.FLAG_MEGAKERNEL)
+    for p in ("beauty", "normal", "tangent", "bitangent"):
+        assert (a[p].view(np.uint32) == b[p].view(np.uint32)).all()
+    assert (a["rng"] == b["rng"]).all() and (a["samples"] == b["samples"]).all()
+    assert a["counters"]["bounce_samples"] == b["counters"]["bounce_samples"]
+    assert a["counters"]["paths"] == b["counters"]["paths"] == 96 * 64 * 5
