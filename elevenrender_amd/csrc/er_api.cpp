@@ -409,7 +409,7 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         uint32_t cus = (uint32_t)prop.multiProcessorCount;
-        s->trace_blocks = cus * 20;   // persistent waves; LDS (8 KB/wave) admits 20 per CU
+        s->trace_blocks = cus * 16;   // persistent waves (LDS 8 KB/wave would admit 20; 16 measured best)
         s->shade_blocks = cus * 8;
         if (const char* e = getenv("ER_TRACE_WAVES_PER_CU")) s->trace_blocks = cus * (uint32_t)std::max(1, atoi(e));   // tuning knob
         if (const char* e = getenv("ER_SHADE_WAVES_PER_CU")) s->shade_blocks = cus * (uint32_t)std::max(1, atoi(e));

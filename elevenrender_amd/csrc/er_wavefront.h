@@ -7,12 +7,15 @@ struct DevScene;
 
 #define ER_WF_FINALIZE_ONLY 0x80000000u   // queue entry flag: no ray this iteration, only finalise the path
 
-// indices into WfState::counts
-#define WF_NC 0       // [2] closest-queue lengths, by parity
-#define WF_NS 2       // [2] shadow-queue lengths, by parity
-#define WF_TT 4       // trace ticket
-#define WF_TS 5       // shade ticket
-#define WF_COUNTS 8
+// indices into WfState::counts.  Every counter sits on its own 128-byte line: they are hammered by
+// device-scope atomics from every wave, and words that share a line serialise on one L2 channel.
+#define WF_LINE 32
+#define WF_NC 0                   // [2] closest-queue lengths, by parity (WF_NC, WF_NC + WF_LINE)
+#define WF_NS (2 * WF_LINE)       // [2] shadow-queue lengths, by parity
+#define WF_TT (4 * WF_LINE)       // trace ticket
+#define WF_TS (5 * WF_LINE)       // shade ticket
+#define WF_COUNTS (8 * WF_LINE)
+#define WF_PAR(p) ((p) * WF_LINE)
 
 // One slot per owned pixel lane (owned_tile_count * 64).  All records are 16 bytes so a lane moves
 // its state with dwordx4 accesses.

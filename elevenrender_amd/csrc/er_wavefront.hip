@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void er_wf_begin(DevScene S, WfState W, uint32_
         W.aov_b[slot] = make_float4(0, 0, 0, 0);
         W.left[slot] = n_samples;
     }
-    unsigned pos = queue_push(&W.counts[WF_NC + 0], valid);
+    unsigned pos = queue_push(&W.counts[WF_NC], valid);
     if (valid) W.q[0][pos] = slot;
 }
 
@@ -125,10 +125,10 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
     const int lane = threadIdx.x;
     uint2* stack = s_stack + lane;
     uint2* spill = W.spill + (size_t)blockIdx.x * (ER_STACK * 64) + lane;
-    const uint32_t nC = W.counts[WF_NC + parity], nS = W.counts[WF_NS + parity];
+    const uint32_t nC = W.counts[WF_NC + WF_PAR(parity)], nS = W.counts[WF_NS + WF_PAR(parity)];
     if (blockIdx.x == 0 && lane == 0) {   // reset what the NEXT shade step appends to / pulls from
-        W.counts[WF_NC + (parity ^ 1)] = 0;
-        W.counts[WF_NS + (parity ^ 1)] = 0;
+        W.counts[WF_NC + WF_PAR(parity ^ 1)] = 0;
+        W.counts[WF_NS + WF_PAR(parity ^ 1)] = 0;
         W.counts[WF_TS] = 0;
     }
     const uint32_t total = nC + nS;
@@ -344,13 +344,16 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
 }
 
 // ---- shade: one bounce-loop step per active slot (src/kernel.cpp:508-645) ----
+#ifndef WF_SHADE_WAVES
+#define WF_SHADE_WAVES 2
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(64) void er_wf_shade(DevScene S, WfState W, uint32_t parity) {
+__global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, WfState W, uint32_t parity) {
     __shared__ int s_stack[ER_STACK * 64];   // only for the rare exact re-trace of an overflowed ray
     const int lane = threadIdx.x;
     int* stack = s_stack + lane;
     unsigned c_nodes = 0, c_tris = 0;
-    const uint32_t nC = W.counts[WF_NC + parity];
+    const uint32_t nC = W.counts[WF_NC + WF_PAR(parity)];
     if (blockIdx.x == 0 && lane == 0) W.counts[WF_TT] = 0;
     const uint32_t wC = (nC + 63) >> 6;
     const uint32_t* qc = W.q[parity];
@@ -359,11 +362,20 @@ __global__ __launch_bounds__(64) void er_wf_shade(DevScene S, WfState W, uint32_
     const size_t npx = (size_t)S.x_res * S.y_res;
     const int hw = S.hdri_tex.width, hh = S.hdri_tex.height;
     unsigned c_paths = 0, c_bounce = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;
+    // tickets (64 slots each) are taken several at a time: one atomic per chunk
+    uint32_t tchunk = wC / (gridDim.x * 4u);
+    tchunk = tchunk < 1u ? 1u : (tchunk > 8u ? 8u : tchunk);
+    uint32_t t_cur = 0, t_end = 0;
     while (true) {
-        uint32_t ticket = 0;
-        if (lane == 0) ticket = atomicAdd(&W.counts[WF_TS], 1u);
-        ticket = __shfl(ticket, 0, 64);
-        if (ticket >= wC) break;
+        if (t_cur >= t_end) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&W.counts[WF_TS], tchunk);
+            base = __shfl(base, 0, 64);
+            t_cur = base;
+            t_end = base + tchunk < wC ? base + tchunk : wC;
+            if (base >= wC) break;
+        }
+        uint32_t ticket = t_cur++;
         uint32_t item = ticket * 64 + lane;
         bool active = item < nC;
         bool push_closest = false, push_shadow = false;
@@ -542,9 +554,9 @@ __global__ __launch_bounds__(64) void er_wf_shade(DevScene S, WfState W, uint32_
                                             __builtin_bit_cast(float, bounce | (pending ? WF_PENDING : 0u)));
             }
         }
-        unsigned pc = queue_push(&W.counts[WF_NC + (parity ^ 1)], push_closest);
+        unsigned pc = queue_push(&W.counts[WF_NC + WF_PAR(parity ^ 1)], push_closest);
         if (push_closest) qn[pc] = next_entry;
-        unsigned ps = queue_push(&W.counts[WF_NS + (parity ^ 1)], push_shadow);
+        unsigned ps = queue_push(&W.counts[WF_NS + WF_PAR(parity ^ 1)], push_shadow);
         if (push_shadow) qsn[ps] = slot;
     }
     unsigned t0 = wave_sum_u(c_paths), t1 = wave_sum_u(c_bounce), t3 = wave_sum_u(c_shaded), t4 = wave_sum_u(c_hdri);
