@@ -156,42 +156,161 @@ struct Builder {
 }  // namespace
 
 // ---- collapse the binary tree into the 8-wide compressed tree (see ErNode8) ----
+// SAH-optimal collapse by dynamic programming (Ylitie, Karras, Laine 2017, section 4.1): for every
+// binary node n and budget i in 1..7, C(n,i) = cheapest way to represent n's subtree as at most i
+// children of a wide node; a child is a leaf (whole subtree, <= ER_BVH_LEAF_MAX triangles) or a wide node.
+namespace {
+const float C_NODE = 1.0f, C_PRIM = 0.3f;
+struct Dp {
+    float C[8];          // C[1..7]
+    uint8_t dec[8];      // dec[1]: 0 = leaf, k>0 = wide node giving k slots to child 0; dec[i>=2]: 0 = same as i-1, k>0 = split k / i-k
+    uint32_t first, count;
+};
+inline float area3(const float* lo, const float* hi) {
+    float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+    return 2.0f * (x * y + x * z + y * z);
+}
+}  // namespace
+
 static void collapse_bvh8(ErBvhBuild* out) {
     out->nodes8.clear();
     out->max_depth8 = 0;
     if (out->nodes.empty()) return;
     std::vector<ErNode>& N2 = out->nodes;
+    const uint32_t n2 = (uint32_t)N2.size();
     const uint32_t tri_count = (uint32_t)out->slot_to_tri.size();
+
+    // ---- bottom-up DP over the binary tree (explicit post-order) ----
+    std::vector<Dp> dp(n2);
+    auto leaf_first = [](int32_t ref) { return ((uint32_t)~ref) >> 3; };
+    auto leaf_count = [](int32_t ref) { return (((uint32_t)~ref) & 7u) + 1u; };
+    auto childC = [&](int32_t ref, float area, int i) -> float {
+        if (ref == ER_BVH_NO_CHILD) return 0.0f;
+        if (ref < 0) return area * (float)leaf_count(ref) * C_PRIM;
+        return dp[ref].C[i];
+    };
+    {
+        std::vector<std::pair<int32_t, int>> st;
+        st.push_back({0, 0});
+        while (!st.empty()) {
+            int32_t n = st.back().first;
+            int phase = st.back().second;
+            const ErNode& nd = N2[n];
+            if (phase == 0) {
+                st.back().second = 1;
+                if (nd.c0 >= 0 && nd.c0 != ER_BVH_NO_CHILD) st.push_back({nd.c0, 0});
+                if (nd.c1 >= 0 && nd.c1 != ER_BVH_NO_CHILD) st.push_back({nd.c1, 0});
+                continue;
+            }
+            st.pop_back();
+            Dp& D = dp[n];
+            const bool has1 = nd.c1 != ER_BVH_NO_CHILD;
+            float a0 = area3(nd.lo0, nd.hi0), a1 = has1 ? area3(nd.lo1, nd.hi1) : 0.0f;
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; a++) {
+                lo[a] = has1 ? std::min(nd.lo0[a], nd.lo1[a]) : nd.lo0[a];
+                hi[a] = has1 ? std::max(nd.hi0[a], nd.hi1[a]) : nd.hi0[a];
+            }
+            float an = area3(lo, hi);
+            uint32_t f0 = nd.c0 < 0 ? leaf_first(nd.c0) : dp[nd.c0].first, k0 = nd.c0 < 0 ? leaf_count(nd.c0) : dp[nd.c0].count;
+            uint32_t f1 = !has1 ? f0 : (nd.c1 < 0 ? leaf_first(nd.c1) : dp[nd.c1].first), k1 = !has1 ? 0 : (nd.c1 < 0 ? leaf_count(nd.c1) : dp[nd.c1].count);
+            D.first = std::min(f0, f1);
+            D.count = k0 + k1;
+            float c_leaf = D.count <= ER_BVH_LEAF_MAX ? an * (float)D.count * C_PRIM : INFINITY;
+            float best = INFINITY;
+            int bk = 1;
+            if (has1) {
+                for (int k = 1; k <= 7; k++) {
+                    float c = childC(nd.c0, a0, k) + childC(nd.c1, a1, 8 - k);
+                    if (c < best) { best = c; bk = k; }
+                }
+            } else {
+                best = childC(nd.c0, a0, 7);
+                bk = 7;
+            }
+            float c_int = an * C_NODE + best;
+            if (c_leaf <= c_int) { D.C[1] = c_leaf; D.dec[1] = 0; } else { D.C[1] = c_int; D.dec[1] = (uint8_t)bk; }
+            for (int i = 2; i <= 7; i++) {
+                float bd = INFINITY;
+                int kk = 0;
+                if (has1)
+                    for (int k = 1; k < i; k++) {
+                        float c = childC(nd.c0, a0, k) + childC(nd.c1, a1, i - k);
+                        if (c < bd) { bd = c; kk = k; }
+                    }
+                if (bd < D.C[i - 1]) { D.C[i] = bd; D.dec[i] = (uint8_t)kk; } else { D.C[i] = D.C[i - 1]; D.dec[i] = 0; }
+            }
+        }
+    }
+
+    // ---- top-down reconstruction, breadth-first so that a node's inner children are consecutive ----
     std::vector<uint32_t> new_order;          // new slot -> old slot
     new_order.reserve(tri_count);
-    struct Child { int32_t ref; float lo[3], hi[3]; int32_t parent2; int which; };
+    struct Child { int32_t ref; float lo[3], hi[3]; bool as_leaf; int32_t parent2; int which; };
     struct Work { uint32_t n8; int32_t n2; uint32_t depth; };
     std::vector<Work> queue;
     out->nodes8.emplace_back();
     queue.push_back(Work{0, 0, 1});
-    auto box_area = [](const Child& c) {
-        float x = c.hi[0] - c.lo[0], y = c.hi[1] - c.lo[1], z = c.hi[2] - c.lo[2];
-        return 2.0f * (x * y + x * z + y * z);
+    // collect(ref, box, budget i) appends the children that represent subtree `ref` within i slots
+    std::vector<Child> ch;
+    struct Item { int32_t ref; float lo[3], hi[3]; int i; int32_t parent2; int which; };
+    auto collect = [&](Item root_item) {
+        std::vector<Item> st{root_item};
+        while (!st.empty()) {
+            Item it = st.back();
+            st.pop_back();
+            Child c;
+            c.ref = it.ref; memcpy(c.lo, it.lo, 12); memcpy(c.hi, it.hi, 12); c.parent2 = it.parent2; c.which = it.which; c.as_leaf = false;
+            if (it.ref < 0) { c.as_leaf = true; ch.push_back(c); continue; }
+            const Dp& D = dp[it.ref];
+            int i = it.i;
+            while (i >= 2 && D.dec[i] == 0) i--;
+            if (i == 1) { c.as_leaf = D.dec[1] == 0; ch.push_back(c); continue; }
+            const ErNode& nd = N2[it.ref];
+            int k = D.dec[i];
+            Item a, b;
+            a.ref = nd.c0; memcpy(a.lo, nd.lo0, 12); memcpy(a.hi, nd.hi0, 12); a.i = k; a.parent2 = it.ref; a.which = 0;
+            b.ref = nd.c1; memcpy(b.lo, nd.lo1, 12); memcpy(b.hi, nd.hi1, 12); b.i = i - k; b.parent2 = it.ref; b.which = 1;
+            st.push_back(b);
+            st.push_back(a);
+        }
     };
-    auto add_children = [&](std::vector<Child>& ch, int32_t n2) {
-        const ErNode& nd = N2[n2];
-        if (nd.c0 != ER_BVH_NO_CHILD) { Child c; c.ref = nd.c0; memcpy(c.lo, nd.lo0, 12); memcpy(c.hi, nd.hi0, 12); c.parent2 = n2; c.which = 0; ch.push_back(c); }
-        if (nd.c1 != ER_BVH_NO_CHILD) { Child c; c.ref = nd.c1; memcpy(c.lo, nd.lo1, 12); memcpy(c.hi, nd.hi1, 12); c.parent2 = n2; c.which = 1; ch.push_back(c); }
+    // rewrites the binary tree's leaf references inside subtree `ref` after its triangles moved by `delta` slots
+    auto shift_leaves = [&](int32_t parent2, int which, int32_t ref, int64_t delta) {
+        struct R { int32_t parent; int which; int32_t ref; };
+        std::vector<R> st{R{parent2, which, ref}};
+        while (!st.empty()) {
+            R r = st.back();
+            st.pop_back();
+            if (r.ref == ER_BVH_NO_CHILD) continue;
+            if (r.ref < 0) {
+                uint32_t nf = (uint32_t)((int64_t)leaf_first(r.ref) + delta), cnt = leaf_count(r.ref);
+                int32_t nref = ~(int32_t)((nf << 3) | (cnt - 1));
+                if (r.which == 0) N2[r.parent].c0 = nref; else N2[r.parent].c1 = nref;
+            } else {
+                st.push_back(R{r.ref, 0, N2[r.ref].c0});
+                st.push_back(R{r.ref, 1, N2[r.ref].c1});
+            }
+        }
     };
     for (size_t qi = 0; qi < queue.size(); qi++) {
         Work w = queue[qi];
         out->max_depth8 = std::max(out->max_depth8, w.depth);
-        std::vector<Child> ch;
-        add_children(ch, w.n2);
-        while (ch.size() < 8) {   // open the inner child with the largest surface area
-            int best = -1;
-            float ba = -1;
-            for (size_t i = 0; i < ch.size(); i++)
-                if (ch[i].ref >= 0) { float a = box_area(ch[i]); if (a > ba) { ba = a; best = (int)i; } }
-            if (best < 0) break;
-            int32_t n2 = ch[best].ref;
-            ch.erase(ch.begin() + best);
-            add_children(ch, n2);
+        ch.clear();
+        {
+            const ErNode& nd = N2[w.n2];
+            const Dp& D = dp[w.n2];
+            const bool has1 = nd.c1 != ER_BVH_NO_CHILD;
+            // the root may itself be a "leaf" by cost; it still becomes one wide node with leaf children
+            int k = D.dec[1] != 0 ? D.dec[1] : (has1 ? 4 : 7);
+            Item a;
+            a.ref = nd.c0; memcpy(a.lo, nd.lo0, 12); memcpy(a.hi, nd.hi0, 12); a.i = k; a.parent2 = w.n2; a.which = 0;
+            collect(a);
+            if (has1) {
+                Item b;
+                b.ref = nd.c1; memcpy(b.lo, nd.lo1, 12); memcpy(b.hi, nd.hi1, 12); b.i = 8 - k; b.parent2 = w.n2; b.which = 1;
+                collect(b);
+            }
         }
         // node bounds
         float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -224,8 +343,7 @@ static void collapse_bvh8(ErBvhBuild* out) {
             if (ext > 0) { (void)std::frexp(ext / 255.0f, &e); }   // 2^e > ext/255
             else e = -126;
             if (e < -126) e = -126;
-            // make sure 255 steps of 2^e reach hi in float arithmetic
-            while (lo[a] + 255.0f * std::ldexp(1.0f, e) < hi[a]) e++;
+            while (lo[a] + 255.0f * std::ldexp(1.0f, e) < hi[a]) e++;   // 255 steps must reach hi in float arithmetic
             nd.e[a] = (uint8_t)(e + 127);
             scale[a] = std::ldexp(1.0f, e);
         }
@@ -247,21 +365,20 @@ static void collapse_bvh8(ErBvhBuild* out) {
                 nd.qlo[a][s8] = (uint8_t)ql;
                 nd.qhi[a][s8] = (uint8_t)qh;
             }
-            if (c.ref >= 0) {
+            if (!c.as_leaf) {
                 nd.imask |= (uint8_t)(1u << s8);
                 nd.meta[s8] = 1;
                 uint32_t idx = (uint32_t)out->nodes8.size();
                 out->nodes8.emplace_back();
                 queue.push_back(Work{idx, c.ref, w.depth + 1});
             } else {
-                uint32_t v = (uint32_t)~c.ref, first = v >> 3, count = (v & 7u) + 1u;
+                uint32_t first = c.ref < 0 ? leaf_first(c.ref) : dp[c.ref].first;
+                uint32_t count = c.ref < 0 ? leaf_count(c.ref) : dp[c.ref].count;
                 nd.meta[s8] = (uint8_t)((count << 5) | tri_off);
                 uint32_t new_first = (uint32_t)new_order.size();
                 for (uint32_t i = 0; i < count; i++) new_order.push_back(first + i);
                 tri_off += count;
-                // keep the binary tree valid over the new triangle order
-                int32_t nref = ~(int32_t)((new_first << 3) | (count - 1));
-                if (c.which == 0) N2[c.parent2].c0 = nref; else N2[c.parent2].c1 = nref;
+                shift_leaves(c.parent2, c.which, c.ref, (int64_t)new_first - (int64_t)first);   // keep the binary tree valid
             }
         }
         out->nodes8[w.n8] = nd;
@@ -285,6 +402,12 @@ void er_build_bvh(const float* vertices, const float* normals, uint32_t tri_coun
     Box sb;
     sb.reset();
     double lift = 0;
+    // absolute part of the box padding: the wide traversal evaluates slab distances as one fused
+    // multiply-add per plane (er_wavefront.hip), whose rounding error is bounded by ~3e-7 x the largest
+    // coordinate in play; 1e-6 x scene scale keeps every box conservative under that arithmetic
+    float vmax = 0;
+    for (size_t i = 0; i < (size_t)tri_count * 9; i++) vmax = std::max(vmax, std::fabs(vertices[i]));
+    const float pad_abs = vmax * 1e-6f;
     for (uint32_t i = 0; i < tri_count; i++) {
         Prim& p = B.prims[i];
         const float* v = vertices + (size_t)i * 9;
@@ -295,7 +418,7 @@ void er_build_bvh(const float* vertices, const float* normals, uint32_t tri_coun
             // conservative padding: Moller-Trumbore (reference src/Tri.h:41-77) accepts hits whose
             // computed position can sit a few ulp outside the exact vertex bounds
             float m = std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a]));
-            float pad = m * 4e-7f + 1e-37f;
+            float pad = std::max(m * 4e-7f + 1e-37f, pad_abs);
             p.lo[a] = b.lo[a] - pad;
             p.hi[a] = b.hi[a] + pad;
             p.c[a] = (v[a] + v[3 + a] + v[6 + a]) * (1.0f / 3.0f);

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
     // per-lane ray state
     bool busy = false, shadow = false;
     uint32_t entry = 0;
-    F3 o = f3s(0), d = f3s(0), idir = f3s(0);
+    F3 o = f3s(0), d = f3s(0), idir = f3s(0), noi = f3s(0);   // noi = -(o * idir)
     float U = 0, limit = 0;          // closest: smallest upper bound so far; shadow: exact distance of the self hit
     int s0 = -1, s1 = -1;            // surviving candidates
     float lo0 = 0, lo1 = 0;
@@ -180,14 +180,17 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
                         float4 rd = shadow ? W.sh_d[entry] : W.ray_d[entry];
                         o = f3(ro.x, ro.y, ro.z);
                         d = f3(rd.x, rd.y, rd.z);
-                        idir = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        // 1/d clamped to +-1e18: a zero (or denormal) component would make the fused plane
+                        // distances inf - inf = NaN; with 1e18 the ray stays inside its slab for any finite t
+                        idir = f3(clampf(1.0f / d.x, -1e18f, 1e18f), clampf(1.0f / d.y, -1e18f, 1e18f), clampf(1.0f / d.z, -1e18f, 1e18f));
+                        noi = f3(-(o.x * idir.x), -(o.y * idir.y), -(o.z * idir.z));
                         skip = shadow ? __builtin_bit_cast(int, ro.w) : -1;
                         limit = shadow ? rd.w : __builtin_inff();
                         U = limit;
                         s0 = -1; s1 = -1; overflow = false;
                         sp = 0;
                         // a positive direction visits low-coordinate children first: they get the high bits
-                        oct7 = (d.x >= 0.0f ? 1u : 0u) | (d.y >= 0.0f ? 2u : 0u) | (d.z >= 0.0f ? 4u : 0u);
+                        oct7 = (idir.x >= 0.0f ? 1u : 0u) | (idir.y >= 0.0f ? 2u : 0u) | (idir.z >= 0.0f ? 4u : 0u);
                         ng_base = 0;
                         ng_bits = (1u << oct7) | (1u << 8);      // the root: slot 0 of a virtual parent, an inner child
                         tg_base = 0; tg_mask = 0;
@@ -296,18 +299,28 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
                     const uint32_t qhx[2] = {__builtin_bit_cast(uint32_t, dd.z), __builtin_bit_cast(uint32_t, dd.w)};
                     const uint32_t qhy[2] = {__builtin_bit_cast(uint32_t, e4.x), __builtin_bit_cast(uint32_t, e4.y)};
                     const uint32_t qhz[2] = {__builtin_bit_cast(uint32_t, e4.z), __builtin_bit_cast(uint32_t, e4.w)};
+                    // Slab test of the eight children.  Box tests only gate the traversal, so any conservative
+                    // evaluation is allowed: the entry/exit planes per axis are picked by the ray's direction sign
+                    // and each plane distance is ONE fused multiply-add, t = q * (2^e * idir) + (p * idir - o * idir);
+                    // its rounding error is covered by the absolute box padding of the builder (er_bvh.cpp).
+                    // (1/d is clamped at ray setup, so no plane distance is NaN for finite inputs.)
+                    const float Ax = sx * idir.x, Ay = sy * idir.y, Az = sz * idir.z;
+                    const float Bx = __builtin_fmaf(a.x, idir.x, noi.x), By = __builtin_fmaf(a.y, idir.y, noi.y), Bz = __builtin_fmaf(a.z, idir.z, noi.z);
+                    const bool posx = (oct7 & 1u) != 0, posy = (oct7 & 2u) != 0, posz = (oct7 & 4u) != 0;
+                    const uint32_t nx[2] = {posx ? qlx[0] : qhx[0], posx ? qlx[1] : qhx[1]}, fx[2] = {posx ? qhx[0] : qlx[0], posx ? qhx[1] : qlx[1]};
+                    const uint32_t ny[2] = {posy ? qly[0] : qhy[0], posy ? qly[1] : qhy[1]}, fy[2] = {posy ? qhy[0] : qly[0], posy ? qhy[1] : qly[1]};
+                    const uint32_t nz[2] = {posz ? qlz[0] : qhz[0], posz ? qlz[1] : qhz[1]}, fz[2] = {posz ? qhz[0] : qlz[0], posz ? qhz[1] : qlz[1]};
                     uint32_t nmask = 0, tmask = 0;
 #pragma unroll
                     for (int s8 = 0; s8 < 8; s8++) {
                         const int w = s8 >> 2, k = s8 & 3;
                         const uint32_t meta = (meta_w[w] >> (8 * k)) & 0xffu;
-                        // decode exactly as the builder verified: p + q * 2^e with one rounding
-                        F3 blo = f3(__builtin_fmaf(ubyte_f(qlx[w], k), sx, a.x), __builtin_fmaf(ubyte_f(qly[w], k), sy, a.y),
-                                    __builtin_fmaf(ubyte_f(qlz[w], k), sz, a.z));
-                        F3 bhi = f3(__builtin_fmaf(ubyte_f(qhx[w], k), sx, a.x), __builtin_fmaf(ubyte_f(qhy[w], k), sy, a.y),
-                                    __builtin_fmaf(ubyte_f(qhz[w], k), sz, a.z));
-                        float tm;
-                        bool hit = box_test(blo, bhi, o, idir, bound, tm) && meta != 0;
+                        const float tnx = __builtin_fmaf(ubyte_f(nx[w], k), Ax, Bx), tfx = __builtin_fmaf(ubyte_f(fx[w], k), Ax, Bx);
+                        const float tny = __builtin_fmaf(ubyte_f(ny[w], k), Ay, By), tfy = __builtin_fmaf(ubyte_f(fy[w], k), Ay, By);
+                        const float tnz = __builtin_fmaf(ubyte_f(nz[w], k), Az, Bz), tfz = __builtin_fmaf(ubyte_f(fz[w], k), Az, Bz);
+                        const float tmin = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+                        const float tmax = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+                        const bool hit = (tmin <= tmax) && (tmax >= 0.0f) && (tmin <= bound) && meta != 0;
                         if (hit) {
                             if ((imask >> s8) & 1u) nmask |= 1u << ((unsigned)s8 ^ oct7);
                             else tmask |= ((1u << (meta >> 5)) - 1u) << (meta & 31u);
