@@ -253,37 +253,47 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
                 const float eps_far = (S.scene_scale + (U < 3.0e38f ? U : 0.0f)) * 4e-6f;
                 const float bound = U + S.max_lift + eps_far;
                 if (tri_step) {
-                    Ray ray;
-                    ray.o = o; ray.d = d;
+                    // Both records are tested with straight-line code (rejections folded into one predicate, exactly
+                    // the comparisons of Tri::hit, src/Tri.h:56-77), then the interval bookkeeping runs once per record.
+                    if (COUNT) c_tris += two ? 2u : 1u;
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
-                        if (k == 1 && (!two || finished)) break;
                         const uint32_t slot = tslot + k;
-                        if (COUNT) c_tris++;
-                        if ((int)slot == skip) continue;
-                        F3 v0 = k == 0 ? f3(a.x, a.y, a.z) : f3(dd.x, dd.y, dd.z);
-                        F3 v1 = k == 0 ? f3(b4.x, b4.y, b4.z) : f3(e4.x, e4.y, e4.z);
-                        F3 v2 = k == 0 ? f3(c.x, c.y, c.z) : f3(f4.x, f4.y, f4.z);
+                        const F3 v0 = k == 0 ? f3(a.x, a.y, a.z) : f3(dd.x, dd.y, dd.z);
+                        const F3 v1 = k == 0 ? f3(b4.x, b4.y, b4.z) : f3(e4.x, e4.y, e4.z);
+                        const F3 v2 = k == 0 ? f3(c.x, c.y, c.z) : f3(f4.x, f4.y, f4.z);
                         const float lift = k == 0 ? b4.w : e4.w;
-                        float u, v, t;
-                        if (!tri_mt(v0, v1, v2, ray, u, v, t)) continue;
+                        const float EPSILON = 0.0000001f;
+                        const F3 edge1 = v1 - v0, edge2 = v2 - v0;
+                        const F3 pvec = cross(d, edge2);
+                        const float det = dot(edge1, pvec);
+                        const float inv_det = 1.0f / det;
+                        const F3 tvec = o - v0;
+                        const float u = dot(tvec, pvec) * inv_det;
+                        const F3 qvec = cross(tvec, edge1);
+                        const float v = dot(d, qvec) * inv_det;
+                        const float t = dot(edge2, qvec) * inv_det;
+                        const bool rejected = (det > -EPSILON && det < EPSILON) || (u < 0 || u > 1) || (v < 0 || (u + v) > 1) || (t < 0);
+                        const bool valid = !rejected && (k == 0 || two) && (int)slot != skip && !finished;
                         const float eps = (S.scene_scale + t) * 4e-6f;
                         const float lo = t - lift - eps, hi = t + lift + eps;
-                        if (shadow) {
-                            if (hi < limit) {                    // certainly nearer than the self hit: occluded
-                                W.occluded[entry] = 1;
-                                finished = true;
-                            } else if (lo < limit) {             // ambiguous: needs the exact metric
-                                if (s0 < 0) s0 = (int)slot; else if (s1 < 0) s1 = (int)slot; else overflow = true;
-                            }
-                        } else if (!(lo > U)) {
-                            U = hi < U ? hi : U;
-                            if (s0 >= 0 && lo0 > U) s0 = -1;
-                            if (s1 >= 0 && lo1 > U) s1 = -1;
-                            if (s0 < 0) { s0 = (int)slot; lo0 = lo; }
-                            else if (s1 < 0) { s1 = (int)slot; lo1 = lo; }
-                            else overflow = true;
-                        }
+                        // shadow query: certainly nearer than the self hit -> occluded; inside the interval -> ambiguous
+                        const bool occl = valid && shadow && hi < limit;
+                        const bool amb = valid && shadow && !(hi < limit) && lo < limit;
+                        // closest query: survives if its lower bound does not exceed the smallest upper bound so far
+                        const bool cand = valid && !shadow && !(lo > U);
+                        U = (cand && hi < U) ? hi : U;
+                        s0 = (cand && s0 >= 0 && lo0 > U) ? -1 : s0;
+                        s1 = (cand && s1 >= 0 && lo1 > U) ? -1 : s1;
+                        const bool want = cand || amb;
+                        const bool ins0 = want && s0 < 0;
+                        const bool ins1 = want && !ins0 && s1 < 0;
+                        overflow = overflow || (want && !ins0 && !ins1);
+                        s0 = ins0 ? (int)slot : s0;
+                        lo0 = ins0 ? lo : lo0;
+                        s1 = ins1 ? (int)slot : s1;
+                        lo1 = ins1 ? lo : lo1;
+                        if (occl) { W.occluded[entry] = 1; finished = true; }
                     }
                 } else {
                     if (COUNT) c_nodes++;
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
                     const uint32_t nx[2] = {posx ? qlx[0] : qhx[0], posx ? qlx[1] : qhx[1]}, fx[2] = {posx ? qhx[0] : qlx[0], posx ? qhx[1] : qlx[1]};
                     const uint32_t ny[2] = {posy ? qly[0] : qhy[0], posy ? qly[1] : qhy[1]}, fy[2] = {posy ? qhy[0] : qly[0], posy ? qhy[1] : qly[1]};
                     const uint32_t nz[2] = {posz ? qlz[0] : qhz[0], posz ? qlz[1] : qhz[1]}, fz[2] = {posz ? qhz[0] : qlz[0], posz ? qhz[1] : qlz[1]};
-                    uint32_t nmask = 0, tmask = 0;
+                    uint32_t hits = 0, tmask = 0;
 #pragma unroll
                     for (int s8 = 0; s8 < 8; s8++) {
                         const int w = s8 >> 2, k = s8 & 3;
@@ -320,12 +330,18 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
                         const float tnz = __builtin_fmaf(ubyte_f(nz[w], k), Az, Bz), tfz = __builtin_fmaf(ubyte_f(fz[w], k), Az, Bz);
                         const float tmin = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
                         const float tmax = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
-                        const bool hit = (tmin <= tmax) && (tmax >= 0.0f) && (tmin <= bound) && meta != 0;
-                        if (hit) {
-                            if ((imask >> s8) & 1u) nmask |= 1u << ((unsigned)s8 ^ oct7);
-                            else tmask |= ((1u << (meta >> 5)) - 1u) << (meta & 31u);
-                        }
+                        const bool hit = (tmin <= tmax) && (tmax >= 0.0f) && (tmin <= bound);
+                        // meta: empty 0 and inner 1 have a zero triangle count, so they add no triangle bits; empty
+                        // slots are not in imask, so they add no node bit either -- no branch on the child kind
+                        const uint32_t leafbits = ((1u << (meta >> 5)) - 1u) << (meta & 31u);
+                        hits |= hit ? (1u << s8) : 0u;
+                        tmask |= hit ? leafbits : 0u;
                     }
+                    // inner hits, moved from bit `slot` to bit `slot ^ oct7` (three conditional swap stages)
+                    uint32_t nmask = hits & imask;
+                    nmask = (oct7 & 1u) ? (((nmask & 0xAAu) >> 1) | ((nmask & 0x55u) << 1)) : nmask;
+                    nmask = (oct7 & 2u) ? (((nmask & 0xCCu) >> 2) | ((nmask & 0x33u) << 2)) : nmask;
+                    nmask = (oct7 & 4u) ? (((nmask & 0xF0u) >> 4) | ((nmask & 0x0Fu) << 4)) : nmask;
                     ng_base = __builtin_bit_cast(uint32_t, b4.x);
                     ng_bits = nmask | (imask << 8);
                     tg_base = __builtin_bit_cast(uint32_t, b4.y);
