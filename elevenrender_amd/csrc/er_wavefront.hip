@@ -248,8 +248,28 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
                     ng_bits = 0;
                     p = S.nodes8 + (size_t)child * 5;
                 }
-                // ---- unified fetch: 96 bytes ----
-                float4 a = p[0], b4 = p[1], c = p[2], dd = p[3], e4 = p[4], f4 = p[5];
+                // ---- unified fetch: up to 96 bytes, as whole 16-byte pieces ----
+                // The vector-memory pipeline (TA/TD/TCP) is the busiest unit of this kernel: every lane gathers
+                // from its own address, so each 16-byte piece costs one cache access whatever its width.  Pieces
+                // are therefore loaded as full dwordx4 (the asm keeps the compiler from splitting them into
+                // narrower loads of only the components used) and only by the lanes that need them:
+                // pieces 0-2 always, 3-4 for nodes and triangle pairs, 5 for triangle pairs.
+                // Lanes that do not need a piece read it from one shared address instead (the first node): equal
+                // addresses coalesce into a single access.  Loads and their wait live in ONE asm statement -- the
+                // compiler treats asm outputs as ready when the statement ends.
+                float4 a, b4, c, dd, e4, f4;
+                const float4* p34 = (!tri_step || two) ? p : S.nodes8;
+                const float4* p5 = (tri_step && two) ? p : S.nodes8;
+                asm volatile("global_load_dwordx4 %0, %6, off\n\t"
+                             "global_load_dwordx4 %1, %6, off offset:16\n\t"
+                             "global_load_dwordx4 %2, %6, off offset:32\n\t"
+                             "global_load_dwordx4 %3, %7, off offset:48\n\t"
+                             "global_load_dwordx4 %4, %7, off offset:64\n\t"
+                             "global_load_dwordx4 %5, %8, off offset:80\n\t"
+                             "s_waitcnt vmcnt(0)"
+                             : "=&v"(a), "=&v"(b4), "=&v"(c), "=&v"(dd), "=&v"(e4), "=&v"(f4)
+                             : "v"(p), "v"(p34), "v"(p5)
+                             : "memory");
                 const float eps_far = (S.scene_scale + (U < 3.0e38f ? U : 0.0f)) * 4e-6f;
                 const float bound = U + S.max_lift + eps_far;
                 if (tri_step) {
