@@ -357,10 +357,14 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     int rc;
     if ((rc = upload(s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * 4, s->stream)) != ER_OK) return rc;
     memset(&isect[n], 0, sizeof(ErTriIsect));
-    if ((rc = upload(s->d_isect, isect.data(), (n + 1) * 3, s->stream)) != ER_OK) return rc;
-    std::vector<float4> n8((bvh.nodes8.size() * 5) + 1, make_float4(0, 0, 0, 0));   // +16 B: the unified fetch reads 96 B
-    if (!bvh.nodes8.empty()) memcpy(n8.data(), bvh.nodes8.data(), bvh.nodes8.size() * sizeof(ErNode8));
-    if ((rc = upload(s->d_nodes8, n8.data(), n8.size(), s->stream)) != ER_OK) return rc;
+    // wide nodes and triangle records share ONE buffer: the wide traversal addresses both with a 32-bit
+    // offset in 16-byte units (its lanes exchange fetch addresses with one ds_bpermute per load)
+    const size_t n8_pieces = bvh.nodes8.size() * 5 + 3;   // + padding: a step fetches 96 B from a node's start
+    std::vector<float4> geom(n8_pieces + (n + 1) * 3, make_float4(0, 0, 0, 0));
+    if (!bvh.nodes8.empty()) memcpy(geom.data(), bvh.nodes8.data(), bvh.nodes8.size() * sizeof(ErNode8));
+    memcpy(geom.data() + n8_pieces, isect.data(), (n + 1) * sizeof(ErTriIsect));
+    if (geom.size() >= (1ull << 30)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: geometry exceeds the 16 GB addressable by the wide traversal");
+    if ((rc = upload(s->d_nodes8, geom.data(), geom.size(), s->stream)) != ER_OK) return rc;
     if (bvh.max_depth8 > ER_BVH_MAX_DEPTH) return fail(ER_ERR_STATE, "er_render_begin: wide BVH deeper than the traversal stack");
     if ((rc = upload(s->d_attr, attr.data(), n * 7, s->stream)) != ER_OK) return rc;
     if ((rc = upload(s->d_materials, s->materials.data(), s->materials.size(), s->stream)) != ER_OK) return rc;
@@ -426,7 +430,8 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     memset(&D, 0, sizeof(D));
     D.nodes = s->d_nodes.p;
     D.nodes8 = s->d_nodes8.p;
-    D.tri_isect = s->d_isect.p;
+    D.tri_isect = s->d_nodes8.p + n8_pieces;
+    D.tri_base_pieces = (uint32_t)n8_pieces;
     D.tri_attr = s->d_attr.p;
     D.tri_count = s->tri_count;
     D.node_count = (uint32_t)bvh.nodes.size();

@@ -12,9 +12,9 @@ struct DevScene;
 #define WF_LINE 32
 #define WF_NC 0                   // [2] closest-queue lengths, by parity (WF_NC, WF_NC + WF_LINE)
 #define WF_NS (2 * WF_LINE)       // [2] shadow-queue lengths, by parity
-#define WF_TT (4 * WF_LINE)       // trace ticket
-#define WF_TS (5 * WF_LINE)       // shade ticket
-#define WF_COUNTS (8 * WF_LINE)
+#define WF_TS (4 * WF_LINE)       // shade ticket
+#define WF_TT (5 * WF_LINE)       // [8] trace tickets, one per XCD range (WF_TT + x * WF_LINE)
+#define WF_COUNTS (13 * WF_LINE)
 #define WF_PAR(p) ((p) * WF_LINE)
 
 // One slot per owned pixel lane (owned_tile_count * 64).  All records are 16 bytes so a lane moves

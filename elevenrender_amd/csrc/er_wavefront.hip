@@ -113,7 +113,10 @@ __global__ __launch_bounds__(64) void er_wf_begin(DevScene S, WfState W, uint32_
 #ifndef WF_REFILL_MIN
 #define WF_REFILL_MIN 16
 #endif
-#define WF_LDS_STACK 16
+#define WF_LDS_STACK 8
+#ifndef WF_COOP
+#define WF_COOP 0   // cooperative LDS-DMA fetch: bit-exact, measured 12 % slower than the per-lane fetch
+#endif
 
 __device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
 
@@ -122,6 +125,11 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
     // group stack: the first WF_LDS_STACK levels in LDS, deeper levels (never reached by SAH trees of the
     // benchmark scenes: 1M triangles -> depth 7) in a per-wave HBM spill area, so depth stays unbounded
     __shared__ uint2 s_stack[WF_LDS_STACK * 64];
+#if WF_COOP
+    // staging area of the cooperative fetch: pieces 0-3 of lane n at [4n + j], pieces 4-5 at [256 + 2n + j]
+    __shared__ float4 s_stage[6 * 64];
+    const uint32_t lds_stage = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)s_stage);
+#endif
     const int lane = threadIdx.x;
     uint2* stack = s_stack + lane;
     uint2* spill = W.spill + (size_t)blockIdx.x * (ER_STACK * 64) + lane;
@@ -156,6 +164,9 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
     chunk = chunk < 64u ? 64u : (chunk > 512u ? 512u : chunk);
     chunk = (chunk + 63u) & ~63u;
     unsigned pool_cur = 0, pool_end = 0;
+    // HW_REG_XCC_ID (hwreg 20, bits 3:0): which XCD this wave runs on
+    const unsigned xcd = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;
+    unsigned steal = 0, cLo = 0, cLen = 0, sLo = 0;
 
     while (true) {
         // ---- refill idle lanes from the wave's local chunk; one global atomic per chunk ----
@@ -163,18 +174,34 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
         unsigned n_idle = __popcll(idle);
         if (!exhausted && (n_idle >= WF_REFILL_MIN || n_idle == 64)) {
             if (pool_cur >= pool_end) {
-                unsigned base = 0;
-                if (lane == 0) base = atomicAdd(&W.counts[WF_TT], chunk);
-                base = __shfl(base, 0, 64);
-                pool_cur = base;
-                pool_end = base + chunk < total ? base + chunk : total;
-                if (base >= total) { exhausted = true; pool_end = pool_cur; }
+                // XCD-aware hand-out: the queue is cut into 8 contiguous ranges, one per XCD (each XCD has its own
+                // L2).  The queue is ordered by pixel tile, so a range is a band of the image and its rays touch a
+                // slab of the scene; a wave drains its own XCD's range first and then steals from the others.
+                // (Placement changes speed only: any wave may process any ray.)
+                while (true) {
+                    const unsigned r = (xcd + steal) & 7u;
+                    // range r = its eighth of the closest-hit queue followed by its eighth of the shadow queue
+                    cLo = (unsigned)(((unsigned long long)nC * r) >> 3);
+                    cLen = (unsigned)(((unsigned long long)nC * (r + 1)) >> 3) - cLo;
+                    sLo = (unsigned)(((unsigned long long)nS * r) >> 3);
+                    const unsigned r_len = cLen + (unsigned)(((unsigned long long)nS * (r + 1)) >> 3) - sLo;
+                    unsigned base = 0;
+                    if (lane == 0) base = atomicAdd(&W.counts[WF_TT + r * WF_LINE], chunk);
+                    base = __shfl(base, 0, 64);
+                    if (base < r_len) {
+                        pool_cur = base;
+                        pool_end = base + chunk < r_len ? base + chunk : r_len;
+                        break;
+                    }
+                    steal++;
+                    if (steal == 8) { exhausted = true; pool_end = pool_cur; break; }
+                }
             }
             if (!busy) {
                 unsigned item = pool_cur + __popcll(idle & ((1ull << lane) - 1ull));
                 if (item < pool_end) {
-                    shadow = item >= nC;
-                    entry = shadow ? qs[item - nC] : qc[item];
+                    shadow = item >= cLen;
+                    entry = shadow ? qs[sLo + item - cLen] : qc[cLo + item];
                     if (!(entry & ER_WF_FINALIZE_ONLY)) {
                         float4 ro = shadow ? W.sh_o[entry] : W.ray_o[entry];
                         float4 rd = shadow ? W.sh_d[entry] : W.ray_d[entry];
@@ -208,9 +235,10 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
             if (exhausted) break;
             continue;
         }
+        // ---- phase 1 (per lane): pop if nothing is pending, then choose this iteration's step ----
+        bool finished = false, do_step = false, tri_step = false, two = false;
+        uint32_t tslot = 0, off = 0;      // off: what to fetch, in 16-byte pieces from S.nodes8 (nodes and triangles share one buffer)
         if (busy) {
-            bool finished = false;
-            // ---- nothing pending in registers: pop a node group, or the ray is done ----
             if (tg_mask == 0 && (ng_bits & 0xffu) == 0) {
                 if (sp == 0) {
                     finished = true;
@@ -223,17 +251,14 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
                 }
             }
             if (!finished) {
-                // ---- choose the step and its address ----
-                const bool tri_step = tg_mask != 0;
-                uint32_t tslot = 0;
-                bool two = false;
-                const float4* p;
+                do_step = true;
+                tri_step = tg_mask != 0;
                 if (tri_step) {
                     unsigned i = __ffs(tg_mask) - 1;
                     two = ((tg_mask >> i) & 2u) != 0;
                     tg_mask &= ~((two ? 3u : 1u) << i);
                     tslot = tg_base + i;
-                    p = S.tri_isect + (size_t)tslot * 3;
+                    off = S.tri_base_pieces + tslot * 3u;
                 } else {
                     uint32_t nmask = ng_bits & 0xffu, imask = (ng_bits >> 8) & 0xffu;
                     unsigned b = 31 - __clz(nmask);
@@ -246,30 +271,76 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
                         sp++;
                     }
                     ng_bits = 0;
-                    p = S.nodes8 + (size_t)child * 5;
+                    off = child * 5u;
                 }
-                // ---- unified fetch: up to 96 bytes, as whole 16-byte pieces ----
-                // The vector-memory pipeline (TA/TD/TCP) is the busiest unit of this kernel: every lane gathers
-                // from its own address, so each 16-byte piece costs one cache access whatever its width.  Pieces
-                // are therefore loaded as full dwordx4 (the asm keeps the compiler from splitting them into
-                // narrower loads of only the components used) and only by the lanes that need them:
-                // pieces 0-2 always, 3-4 for nodes and triangle pairs, 5 for triangle pairs.
-                // Lanes that do not need a piece read it from one shared address instead (the first node): equal
-                // addresses coalesce into a single access.  Loads and their wait live in ONE asm statement -- the
-                // compiler treats asm outputs as ready when the statement ends.
-                float4 a, b4, c, dd, e4, f4;
-                const float4* p34 = (!tri_step || two) ? p : S.nodes8;
-                const float4* p5 = (tri_step && two) ? p : S.nodes8;
-                asm volatile("global_load_dwordx4 %0, %6, off\n\t"
-                             "global_load_dwordx4 %1, %6, off offset:16\n\t"
-                             "global_load_dwordx4 %2, %6, off offset:32\n\t"
-                             "global_load_dwordx4 %3, %7, off offset:48\n\t"
-                             "global_load_dwordx4 %4, %7, off offset:64\n\t"
-                             "global_load_dwordx4 %5, %8, off offset:80\n\t"
-                             "s_waitcnt vmcnt(0)"
-                             : "=&v"(a), "=&v"(b4), "=&v"(c), "=&v"(dd), "=&v"(e4), "=&v"(f4)
-                             : "v"(p), "v"(p34), "v"(p5)
-                             : "memory");
+            }
+        }
+        // ---- phase 2 (whole wave): fetch up to 96 bytes per stepping lane ----
+        // The vector-memory pipeline (TA/TD/TCP) is the busiest unit of this kernel, and it pays per cache
+        // access, not per byte: a lane gathering six 16-byte pieces from its own line costs six accesses.
+        float4 a, b4, c, dd, e4, f4;
+#if WF_COOP
+        {
+            // Cooperative fetch: lanes exchange their offsets (ds_bpermute) so that FOUR adjacent lanes read the
+            // 64 contiguous bytes of one lane's record (pieces 0-3) and TWO adjacent lanes read its pieces 4-5;
+            // adjacent lanes on one line coalesce into a single cache access (16 resp. 32 accesses per load
+            // instead of 64).  The loads are LDS-DMA (global_load_lds_dwordx4: lane l writes 16 bytes at
+            // M0 + 16 l), so load k of the first four lands the records of lanes 16k..16k+15 at s_stage[4n + j];
+            // every lane then reads its own 96 bytes back with six ds_read_b128.
+            const bool need34 = do_step && (!tri_step || two), need5 = do_step && tri_step && two;
+            const uint32_t offp = (do_step ? off : 0u) | (need34 ? 0x80000000u : 0u) | (need5 ? 0x40000000u : 0u);
+            const float4* g[6];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((16 * k + (lane >> 2)) * 4, (int)offp);
+                g[k] = S.nodes8 + (v & 0x3fffffffu) + (lane & 3);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((32 * k + (lane >> 1)) * 4, (int)offp);
+                const bool needed = (lane & 1) ? (v & 0x40000000u) != 0 : (v & 0x80000000u) != 0;
+                g[4 + k] = S.nodes8 + (needed ? (v & 0x3fffffffu) : 0u) + 4 + (lane & 1);   // unneeded -> one shared line
+            }
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\t"
+                         "s_mov_b32 m0, %7\n\t" "s_nop 0\n\t" "global_load_lds_dwordx4 %1, off\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t" "s_nop 0\n\t" "global_load_lds_dwordx4 %2, off\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t" "s_nop 0\n\t" "global_load_lds_dwordx4 %3, off\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t" "s_nop 0\n\t" "global_load_lds_dwordx4 %4, off\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t" "s_nop 0\n\t" "global_load_lds_dwordx4 %5, off\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t" "s_nop 0\n\t" "global_load_lds_dwordx4 %6, off\n\t"
+                         "s_mov_b32 m0, %0\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&s"(keep)
+                         : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "s"(lds_stage)
+                         : "memory", "scc");
+            const float4* mine = s_stage + lane * 4;
+            a = mine[0]; b4 = mine[1]; c = mine[2]; dd = mine[3];
+            const float4* mine2 = s_stage + 256 + lane * 2;
+            e4 = mine2[0]; f4 = mine2[1];
+        }
+#else
+        {
+            // Per-lane fetch: whole dwordx4 pieces in ONE asm statement with their wait (the compiler treats asm
+            // outputs as ready when the statement ends); lanes that do not need a piece read one shared address.
+            const float4* p = S.nodes8 + (do_step ? off : 0u);
+            const float4* p34 = (do_step && (!tri_step || two)) ? p : S.nodes8;
+            const float4* p5 = (do_step && tri_step && two) ? p : S.nodes8;
+            asm volatile("global_load_dwordx4 %0, %6, off\n\t"
+                         "global_load_dwordx4 %1, %6, off offset:16\n\t"
+                         "global_load_dwordx4 %2, %6, off offset:32\n\t"
+                         "global_load_dwordx4 %3, %7, off offset:48\n\t"
+                         "global_load_dwordx4 %4, %7, off offset:64\n\t"
+                         "global_load_dwordx4 %5, %8, off offset:80\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(a), "=&v"(b4), "=&v"(c), "=&v"(dd), "=&v"(e4), "=&v"(f4)
+                         : "v"(p), "v"(p34), "v"(p5)
+                         : "memory");
+        }
+#endif
+        // ---- phase 3 (per lane): the step itself ----
+        if (busy) {
+            if (do_step) {
                 const float eps_far = (S.scene_scale + (U < 3.0e38f ? U : 0.0f)) * 4e-6f;
                 const float bound = U + S.max_lift + eps_far;
                 if (tri_step) {
@@ -403,7 +474,7 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
     int* stack = s_stack + lane;
     unsigned c_nodes = 0, c_tris = 0;
     const uint32_t nC = W.counts[WF_NC + WF_PAR(parity)];
-    if (blockIdx.x == 0 && lane == 0) W.counts[WF_TT] = 0;
+    if (blockIdx.x == 0 && lane < 8) W.counts[WF_TT + lane * WF_LINE] = 0;
     const uint32_t wC = (nC + 63) >> 6;
     const uint32_t* qc = W.q[parity];
     uint32_t* qn = W.q[parity ^ 1];
