@@ -160,7 +160,10 @@ struct Builder {
 // binary node n and budget i in 1..7, C(n,i) = cheapest way to represent n's subtree as at most i
 // children of a wide node; a child is a leaf (whole subtree, <= ER_BVH_LEAF_MAX triangles) or a wide node.
 namespace {
-const float C_NODE = 1.0f, C_PRIM = 0.3f;
+#ifndef ER_C_PRIM
+#define ER_C_PRIM 0.3f
+#endif
+const float C_NODE = 1.0f, C_PRIM = ER_C_PRIM;
 struct Dp {
     float C[8];          // C[1..7]
     uint8_t dec[8];      // dec[1]: 0 = leaf, k>0 = wide node giving k slots to child 0; dec[i>=2]: 0 = same as i-1, k>0 = split k / i-k

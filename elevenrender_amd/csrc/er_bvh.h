@@ -16,7 +16,9 @@
 #include <vector>
 
 #define ER_BVH_MAX_DEPTH 32   // also the LDS stack depth per lane
-#define ER_BVH_LEAF_MAX 4
+#ifndef ER_BVH_LEAF_MAX
+#define ER_BVH_LEAF_MAX 2   // measured on C2: 2 -> 838, 3 -> 792, 4 -> 764 Msamples/s (fewer triangle fetches per ray)
+#endif
 #define ER_BVH_NO_CHILD 0x7fffffff
 
 // child reference: >= 0 inner node index; < 0 leaf: ~((first_slot << 3) | (count-1)); ER_BVH_NO_CHILD = empty
