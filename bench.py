@@ -27,11 +27,19 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def algorithmic_bytes(c, hdri_texels):
-    """DESIGN.md "Roofline accounting": bytes the traversal/shading algorithm must touch."""
+def trace_bytes(c):
+    """Algorithmic bytes of the dominant kernel er_wf_trace (DESIGN.md "Roofline accounting"): per node step one
+    80-byte ErNode8, per triangle test one 48-byte record, per ray 32 bytes of ray in and 8 bytes of result out."""
+    return 80 * c["node_visits"] + 48 * c["tri_tests"] + 40 * c["rays"]
+
+
+def path_bytes(c, hdri_texels):
+    """Algorithmic bytes of the whole per-sample path: traversal + per shaded hit the 48-byte record and the
+    112-byte attribute record + texels + the HDRI CDF search (the reference's ceil(log2 P) 4-byte probes) +
+    per finished path 144 bytes of framebuffer/RNG/sample-count read-modify-write."""
     cdf_steps = max(1, math.ceil(math.log2(max(2, hdri_texels))))
-    return (64 * c["node_visits"] + 48 * c["tri_tests"] + 112 * c["shaded_hits"] + 12 * c["texel_fetches"]
-            + 4 * cdf_steps * c["hdri_samples"] + 144 * c["paths"])
+    return (trace_bytes(c) + 160 * c["shaded_hits"] + 12 * c["texel_fetches"] + 4 * cdf_steps * c["hdri_samples"]
+            + 144 * c["paths"])
 
 
 def cpu_baseline(scene, max_bounces, budget_s=18.0):
@@ -100,7 +108,7 @@ def main():
 
     scene = scenes.soup(args.tris, args.width, args.height, seed=12345)
     pars = render.RenderParameters(sampleTarget=256, max_bounces=args.max_bounces, device=f"hip:{local_rank}",
-                                   rank=rank, world=world)
+                                   rank=rank, world=world, flags=abi.FLAG_PROFILE)
     rm = render.RenderingManager(pars)
     rm.start_rendering(scene)
     accel = rm.accel_info()
@@ -122,6 +130,7 @@ def main():
     else:
         rm.render(args.steps, blocking=False)
     kernel_ms = rm.wait()
+    prof = rm.profile()      # per-kernel device time of the timed region (HIP events on the library's stream)
     sync_all()
     elapsed = time.perf_counter() - t0
     c_after = rm.counters()
@@ -167,11 +176,21 @@ def main():
         ci = inst.counters()
         inst.close()
         hdri_texels = scene.hdri[1] * scene.hdri[2]
-        bytes_per_sample = algorithmic_bytes(ci, hdri_texels) / max(1, ci["bounce_samples"])
         my_samples = c_after["bounce_samples"] - c_before["bounce_samples"]
-        bytes_per_launch = bytes_per_sample * my_samples / launches
-        kernel_s_per_launch = kernel_ms * 1e-3 / launches
-        achieved = bytes_per_launch / kernel_s_per_launch / 1e9
+        my_rays = c_after["rays"] - c_before["rays"]
+        # per-ray statistics of the instrumented replay scale the timed region's ray count
+        trace_b = trace_bytes(ci) / max(1, ci["rays"]) * my_rays
+        path_b = path_bytes(ci, hdri_texels) / max(1, ci["bounce_samples"]) * my_samples
+        t_launches = max(1, prof["trace_launches"])
+        trace_ms_avg = prof["trace_ms"] / t_launches
+        achieved = (trace_b / t_launches) / (trace_ms_avg * 1e-3) / 1e9 if trace_ms_avg > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes
+        if os.path.exists(tf) and world == 1 and args.tris == 1_000_000:
+            try:
+                traffic = json.load(open(tf)).get("er_wf_trace_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
         value = samples / elapsed / 1e6
         result = {
             "metric": "Msamples/sec (rays traced x bounces) at 1920x1080, 1M-tri scene",
@@ -180,17 +199,19 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C2: {args.tris}-triangle random soup + 2048x1024 sky HDRI, {args.width}x{args.height}, "
                                    f"max_bounces {args.max_bounces}, 1 step = 1 spp pass (config total 256 spp), seed 12345",
-                       "sharding": f"8x8 pixel tiles, (tx+ty) % {world}", "launches_in_timed_region": launches},
+                       "sharding": f"8x8 pixel tiles, (tx+ty) % {world}", "calls_in_timed_region": launches},
             "paths_per_s": round(paths / elapsed, 1), "rays_per_s": round(rays / elapsed, 1),
             "mean_path_length": round(samples / max(1, paths), 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "er_render_kernel", "kernel_ms_per_launch": round(kernel_ms / launches, 4),
-                         "algorithmic_bytes_per_sample": round(bytes_per_sample, 1),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "er_wf_trace", "launches": prof["trace_launches"],
+                         "avg_launch_ms": round(trace_ms_avg, 5), "algorithmic_bytes_per_launch": round(trace_b / t_launches, 1),
+                         "trace_ms_total": round(prof["trace_ms"], 3), "shade_ms_total": round(prof["shade_ms"], 3),
+                         "whole_path_GBps": round(path_b / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else None,
                          "node_visits_per_ray": round(ci["node_visits"] / max(1, ci["rays"]), 2),
                          "tri_tests_per_ray": round(ci["tri_tests"] / max(1, ci["rays"]), 2)},
-            "accel": {"nodes": accel["node_count"], "leaves": accel["leaf_count"], "max_depth": accel["max_depth"],
-                      "build_ms": round(accel["build_ms"], 1), "upload_ms": round(accel["upload_ms"], 2)},
+            "accel": {"nodes": accel["node_count"], "node_bytes": accel["node_bytes"], "leaves": accel["leaf_count"],
+                      "max_depth": accel["max_depth"], "build_ms": round(accel["build_ms"], 1), "upload_ms": round(accel["upload_ms"], 2)},
             "readback_ms": round(readback_ms, 2), "beauty_mean": beauty_mean,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -17,7 +17,7 @@ ER_OK = 0
 ER_ERR_INVALID_ARG, ER_ERR_NO_DEVICE, ER_ERR_HIP, ER_ERR_STATE, ER_ERR_OOM = -1, -2, -3, -4, -5
 PASS_BEAUTY, PASS_DENOISE, PASS_NORMAL, PASS_TANGENT, PASS_BITANGENT, PASS_COUNT = 0, 1, 2, 3, 4, 5
 PASS_NAMES = {"beauty": 0, "denoise": 1, "normal": 2, "tangent": 3, "bitangent": 4}
-FLAG_POINT_LIGHTS, FLAG_COUNTERS, FLAG_MEGAKERNEL = 1, 2, 4
+FLAG_POINT_LIGHTS, FLAG_COUNTERS, FLAG_MEGAKERNEL, FLAG_PROFILE = 1, 2, 4, 8
 
 
 class ErVec3(C.Structure):
@@ -82,6 +82,10 @@ class ErCounters(C.Structure):
                                           "shaded_hits", "texel_fetches", "hdri_samples")]
 
 
+class ErProfile(C.Structure):
+    _fields_ = [("trace_ms", C.c_float), ("shade_ms", C.c_float), ("trace_launches", C.c_uint32), ("shade_launches", C.c_uint32)]
+
+
 class ErAccelInfo(C.Structure):
     _fields_ = [("node_count", C.c_uint32), ("node_bytes", C.c_uint32), ("leaf_count", C.c_uint32),
                 ("max_depth", C.c_uint32), ("tri_record_bytes", C.c_uint32), ("build_ms", C.c_float),
@@ -111,6 +115,7 @@ SYMBOLS = {
     "er_unpack_owned": (C.c_int, [_P, C.c_int, C.c_uint32, _P]),
     "er_get_counters": (C.c_int, [_P, C.POINTER(ErCounters)]),
     "er_accel_info": (C.c_int, [_P, C.POINTER(ErAccelInfo)]),
+    "er_get_profile": (C.c_int, [_P, C.POINTER(ErProfile)]),
 }
 
 _lib = None

@@ -129,6 +129,9 @@ struct ErScene {
     DevBuf<uint32_t> d_guide;
     WfState wf{};
     uint32_t trace_blocks = 0, shade_blocks = 0;
+    std::vector<hipEvent_t> prof_events;   // ER_FLAG_PROFILE: e[3i], e[3i+1], e[3i+2] = before trace, between, after shade
+    size_t prof_used = 0;
+    ErProfile profile{};
     std::map<uint32_t, DevBuf<uint32_t>> d_rank_tiles;   // tile lists of other ranks (for unpack)
     std::mutex mtx;
 
@@ -146,6 +149,9 @@ struct ErScene {
         d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release();
         for (auto& kv : d_rank_tiles) kv.second.release();
         d_rank_tiles.clear();
+        for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
+        prof_events.clear();
+        prof_used = 0;
         if (ev_start) (void)hipEventDestroy(ev_start);
         if (ev_stop) (void)hipEventDestroy(ev_stop);
         if (stream) (void)hipStreamDestroy(stream);
@@ -467,10 +473,10 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     (void)hipEventDestroy(u0);
     (void)hipEventDestroy(u1);
 
-    s->accel.node_count = (uint32_t)bvh.nodes.size();
-    s->accel.node_bytes = sizeof(ErNode);
+    s->accel.node_count = (uint32_t)bvh.nodes8.size();
+    s->accel.node_bytes = sizeof(ErNode8);
+    s->accel.max_depth = bvh.max_depth8;
     s->accel.leaf_count = bvh.leaf_count;
-    s->accel.max_depth = bvh.max_depth;
     s->accel.tri_record_bytes = sizeof(ErTriIsect);
     s->accel.build_ms = (float)bvh.build_ms;
     s->accel.upload_ms = up_ms;
@@ -495,8 +501,21 @@ int er_render_samples_async(ErScene* s, uint32_t n) {
         // a path takes at most max_bounces ray steps plus one finalize-only step
         const uint32_t iters = n * (s->params.max_bounces + 1);
         er_launch_wf_begin(s->dev, s->wf, n, s->stream);
-        for (uint32_t it = 0; it < iters; it++)
-            er_launch_wf_iteration(s->dev, s->wf, it & 1, count, s->trace_blocks, s->shade_blocks, s->stream);
+        const bool prof = (s->params.flags & ER_FLAG_PROFILE) != 0;
+        if (prof) {
+            while (s->prof_events.size() < s->prof_used + 3 * (size_t)iters) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                s->prof_events.push_back(e);
+            }
+        }
+        for (uint32_t it = 0; it < iters; it++) {
+            if (prof) HIP_TRY(hipEventRecord(s->prof_events[s->prof_used++], s->stream));
+            er_launch_wf_trace(s->dev, s->wf, it & 1, count, s->trace_blocks, s->stream);
+            if (prof) HIP_TRY(hipEventRecord(s->prof_events[s->prof_used++], s->stream));
+            er_launch_wf_shade(s->dev, s->wf, it & 1, count, s->shade_blocks, s->stream);
+            if (prof) HIP_TRY(hipEventRecord(s->prof_events[s->prof_used++], s->stream));
+        }
     }
     HIP_TRY(hipGetLastError());
     return ER_OK;
@@ -517,6 +536,17 @@ int er_wait(ErScene* s, float* elapsed_ms) {
         HIP_TRY(hipStreamSynchronize(s->stream));
     }
     if (elapsed_ms) *elapsed_ms = ms;
+    s->profile = ErProfile{};
+    for (size_t i = 0; i + 2 < s->prof_used; i += 3) {
+        float a = 0, b = 0;
+        HIP_TRY(hipEventElapsedTime(&a, s->prof_events[i], s->prof_events[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&b, s->prof_events[i + 1], s->prof_events[i + 2]));
+        s->profile.trace_ms += a;
+        s->profile.shade_ms += b;
+        s->profile.trace_launches++;
+        s->profile.shade_launches++;
+    }
+    s->prof_used = 0;
     return ER_OK;
 }
 
@@ -617,6 +647,13 @@ int er_get_counters(ErScene* s, ErCounters* out) {
     out->paths = c.paths; out->bounce_samples = c.bounce_samples; out->rays = c.rays; out->node_visits = c.node_visits;
     out->tri_tests = c.tri_tests; out->shaded_hits = c.shaded_hits; out->texel_fetches = c.texel_fetches;
     out->hdri_samples = c.hdri_samples;
+    return ER_OK;
+}
+
+int er_get_profile(ErScene* s, ErProfile* out) {
+    if (!s || !out) return fail(ER_ERR_INVALID_ARG, "er_get_profile: NULL argument");
+    if (!s->begun) return fail(ER_ERR_STATE, "er_get_profile: er_render_begin has not succeeded");
+    *out = s->profile;
     return ER_OK;
 }
 

@@ -44,5 +44,5 @@ struct WfState {
 };
 
 void er_launch_wf_begin(const DevScene& S, const WfState& W, uint32_t n_samples, hipStream_t stream);
-void er_launch_wf_iteration(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t trace_blocks,
-                            uint32_t shade_blocks, hipStream_t stream);
+void er_launch_wf_trace(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t blocks, hipStream_t stream);
+void er_launch_wf_shade(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t blocks, hipStream_t stream);

@@ -695,14 +695,13 @@ void er_launch_wf_begin(const DevScene& S, const WfState& W, uint32_t n_samples,
     (void)hipMemsetAsync(W.counts, 0, WF_COUNTS * sizeof(uint32_t), stream);
     hipLaunchKernelGGL(er_wf_begin, dim3(S.owned_tile_count), dim3(64), 0, stream, S, W, n_samples);
 }
-void er_launch_wf_iteration(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t trace_blocks,
-                            uint32_t shade_blocks, hipStream_t stream) {
+void er_launch_wf_trace(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t blocks, hipStream_t stream) {
     if (S.owned_tile_count == 0) return;
-    if (count) {
-        hipLaunchKernelGGL(er_wf_trace<true>, dim3(trace_blocks), dim3(64), 0, stream, S, W, parity);
-        hipLaunchKernelGGL(er_wf_shade<true>, dim3(shade_blocks), dim3(64), 0, stream, S, W, parity);
-    } else {
-        hipLaunchKernelGGL(er_wf_trace<false>, dim3(trace_blocks), dim3(64), 0, stream, S, W, parity);
-        hipLaunchKernelGGL(er_wf_shade<false>, dim3(shade_blocks), dim3(64), 0, stream, S, W, parity);
-    }
+    if (count) hipLaunchKernelGGL(er_wf_trace<true>, dim3(blocks), dim3(64), 0, stream, S, W, parity);
+    else hipLaunchKernelGGL(er_wf_trace<false>, dim3(blocks), dim3(64), 0, stream, S, W, parity);
+}
+void er_launch_wf_shade(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t blocks, hipStream_t stream) {
+    if (S.owned_tile_count == 0) return;
+    if (count) hipLaunchKernelGGL(er_wf_shade<true>, dim3(blocks), dim3(64), 0, stream, S, W, parity);
+    else hipLaunchKernelGGL(er_wf_shade<false>, dim3(blocks), dim3(64), 0, stream, S, W, parity);
 }

@@ -119,6 +119,11 @@ class RenderingManager:
         abi.check(self.lib.er_get_counters(self.handle, C.byref(c)))
         return {n: int(getattr(c, n)) for n, _ in abi.ErCounters._fields_}
 
+    def profile(self):
+        pr = abi.ErProfile()
+        abi.check(self.lib.er_get_profile(self.handle, C.byref(pr)))
+        return {n: getattr(pr, n) for n, _ in abi.ErProfile._fields_}
+
     def accel_info(self):
         a = abi.ErAccelInfo()
         abi.check(self.lib.er_accel_info(self.handle, C.byref(a)))

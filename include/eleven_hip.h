@@ -113,6 +113,7 @@ typedef struct ErSceneDesc {
 #define ER_FLAG_POINT_LIGHTS 1u   /* extension, default off = reference behaviour */
 #define ER_FLAG_COUNTERS     2u   /* count node visits / triangle tests (slower kernel variant) */
 #define ER_FLAG_MEGAKERNEL   4u   /* one fused kernel per call instead of the wavefront schedule (same results) */
+#define ER_FLAG_PROFILE      8u   /* bracket every trace / shade launch with HIP events (see er_get_profile) */
 
 /* reference RenderParameters (src/kernel.h:51-69) + what the MI355X build adds. */
 typedef struct ErRenderParams {
@@ -188,6 +189,14 @@ int er_pack_owned(ErScene* scene, int pass, void* dev_dst);
 int er_unpack_owned(ErScene* scene, int pass, uint32_t src_rank, const void* dev_src);
 
 int er_get_counters(ErScene* scene, ErCounters* out);
+
+/* Per-kernel device time of the launches enqueued since the previous er_wait, measured with HIP events on
+ * the library's stream (needs ER_FLAG_PROFILE; valid after er_wait). */
+typedef struct ErProfile {
+    float trace_ms, shade_ms;          /* summed over launches */
+    uint32_t trace_launches, shade_launches;
+} ErProfile;
+int er_get_profile(ErScene* scene, ErProfile* out);
 
 /* Description of the built acceleration structure, for roofline accounting. */
 typedef struct ErAccelInfo {
