@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=18.0)
     ap.add_argument("--per-step-launch", action="store_true", help="one launch per step instead of one launch for all K steps")
+    ap.add_argument("--sim-world", type=int, default=0, help="(diagnostic) render only rank --sim-rank's tiles of this many, no collective")
+    ap.add_argument("--sim-rank", type=int, default=0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,8 +109,9 @@ def main():
         torch.cuda.set_device(local_rank)
 
     scene = scenes.soup(args.tris, args.width, args.height, seed=12345)
+    shard_rank, shard_world = (args.sim_rank, args.sim_world) if (args.sim_world > 1 and world == 1) else (rank, world)
     pars = render.RenderParameters(sampleTarget=256, max_bounces=args.max_bounces, device=f"hip:{local_rank}",
-                                   rank=rank, world=world, flags=abi.FLAG_PROFILE)
+                                   rank=shard_rank, world=shard_world, flags=abi.FLAG_PROFILE)
     rm = render.RenderingManager(pars)
     rm.start_rendering(scene)
     accel = rm.accel_info()
@@ -168,7 +171,7 @@ def main():
     if rank == 0:
         # ---- roofline: algorithmic bytes per launch from an instrumented replay of the same samples ----
         inst = render.RenderingManager(render.RenderParameters(sampleTarget=256, max_bounces=args.max_bounces,
-                                                               device=f"hip:{local_rank}", rank=rank, world=world,
+                                                               device=f"hip:{local_rank}", rank=shard_rank, world=shard_world,
                                                                flags=abi.FLAG_COUNTERS))
         inst.start_rendering(scene)
         n_inst = min(2, args.steps)
