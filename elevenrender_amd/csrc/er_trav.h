@@ -1,0 +1,259 @@
+// er_trav.h -- one traversal step of the 8-wide compressed BVH, shared by the wavefront trace kernel
+// (er_wavefront.hip) and the fused lane-asynchronous kernel (er_fused.hip).
+//
+// A lane owns one ray at a time and advances it by ONE step per call sequence
+//     trav_choose  (pop if nothing is pending; pick a NODE step or a TRIANGLE step and its address)
+//     trav_fetch   (up to 96 bytes from that address, whole 16-byte pieces)
+//     trav_apply   (decode + 8 box tests, or Moller-Trumbore on one/two records + interval bookkeeping)
+// Traversal state (after Ylitie, Karras, Laine 2017): the current NODE GROUP (first-child index + mask of hit
+// inner children, stored at bit `slot ^ octant` so the highest set bit is the nearest child) and the current
+// TRIANGLE GROUP (first slot + mask).  Only node groups are pushed, at most one per level, so the stack is
+// bounded by the tree depth (first WF_LDS_STACK levels in LDS, deeper ones in an HBM spill area).
+//
+// Nearest hit under the reference's metric m = |Hit.position - origin| (reference src/BVH.cpp:114) without
+// fetching normals: for a triangle with lift bound l (er_bvh.h) a Moller-Trumbore hit at parameter t has
+// m in [t - l - eps, t + l + eps].  The state keeps U = the smallest upper bound seen and the (at most two)
+// candidates whose lower bound is <= U; almost always one survives and it is the reference's winner.  Two
+// survivors -> the caller compares their exact metrics (exact_distance); more -> the caller re-traces the ray
+// with the exact scalar routine (trace<> in er_device.h).
+#pragma once
+#include "er_device.h"
+
+#define WF_LDS_STACK 8
+
+namespace erd {
+
+struct Trav {
+    F3 o, d, idir, noi;              // ray; clamped 1/d; -(o * idir)
+    float U, limit, lo0, lo1;        // closest: smallest upper bound so far; shadow: exact distance of the self hit
+    int s0, s1, skip;                // surviving candidates; slot to ignore (shadow query: the triangle the ray leaves)
+    uint32_t ng_base, ng_bits;       // node group: first child index; hit mask (bits 0-7, octant order) | imask << 8
+    uint32_t tg_base, tg_mask;       // triangle group: first slot; mask of slots still to test
+    uint32_t oct7;
+    int sp;
+    bool overflow, shadow;
+};
+
+__device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
+
+ERD void trav_begin(Trav& T, F3 o, F3 d, bool shadow, int skip, float limit) {
+    T.o = o;
+    T.d = d;
+    // 1/d clamped to +-1e18: a zero (or denormal) component would make the fused plane distances
+    // inf - inf = NaN; with 1e18 the ray stays inside its slab for any finite t
+    T.idir = f3(clampf(1.0f / d.x, -1e18f, 1e18f), clampf(1.0f / d.y, -1e18f, 1e18f), clampf(1.0f / d.z, -1e18f, 1e18f));
+    T.noi = f3(-(o.x * T.idir.x), -(o.y * T.idir.y), -(o.z * T.idir.z));
+    T.skip = skip;
+    T.limit = limit;
+    T.U = limit;
+    T.s0 = -1; T.s1 = -1; T.lo0 = 0; T.lo1 = 0;
+    T.overflow = false;
+    T.shadow = shadow;
+    T.sp = 0;
+    // a positive direction visits low-coordinate children first: they get the high bits
+    T.oct7 = (T.idir.x >= 0.0f ? 1u : 0u) | (T.idir.y >= 0.0f ? 2u : 0u) | (T.idir.z >= 0.0f ? 4u : 0u);
+    T.ng_base = 0;
+    T.ng_bits = (1u << T.oct7) | (1u << 8);      // the root: slot 0 of a virtual parent, an inner child
+    T.tg_base = 0; T.tg_mask = 0;
+}
+
+// phase 1.  Returns true if the lane takes a step this iteration; `finished` = the ray is complete (stack empty).
+ERD bool trav_choose(Trav& T, const DevScene& S, uint2* stack, uint2* spill, bool& finished, bool& tri_step, bool& two,
+                     uint32_t& tslot, uint32_t& off) {
+    finished = false; tri_step = false; two = false; tslot = 0; off = 0;
+    if (T.tg_mask == 0 && (T.ng_bits & 0xffu) == 0) {
+        if (T.sp == 0) { finished = true; return false; }
+        T.sp--;
+        uint2 g = T.sp < WF_LDS_STACK ? stack[T.sp * 64] : spill[(T.sp - WF_LDS_STACK) * 64];
+        T.ng_base = g.x;
+        T.ng_bits = g.y;
+    }
+    tri_step = T.tg_mask != 0;
+    if (tri_step) {
+        unsigned i = __ffs(T.tg_mask) - 1;
+        two = ((T.tg_mask >> i) & 2u) != 0;
+        T.tg_mask &= ~((two ? 3u : 1u) << i);
+        tslot = T.tg_base + i;
+        off = S.tri_base_pieces + tslot * 3u;
+    } else {
+        uint32_t nmask = T.ng_bits & 0xffu, imask = (T.ng_bits >> 8) & 0xffu;
+        unsigned b = 31 - __clz(nmask);
+        nmask &= ~(1u << b);
+        unsigned s8 = b ^ T.oct7;
+        uint32_t child = T.ng_base + __popc(imask & ((1u << s8) - 1u));
+        if (nmask) {                       // siblings still to visit: one stack entry for the whole group
+            uint2 g = make_uint2(T.ng_base, nmask | (imask << 8));
+            if (T.sp < WF_LDS_STACK) stack[T.sp * 64] = g; else spill[(T.sp - WF_LDS_STACK) * 64] = g;
+            T.sp++;
+        }
+        T.ng_bits = 0;
+        off = child * 5u;
+    }
+    return true;
+}
+
+// phase 2: per-lane fetch of up to six whole dwordx4 pieces.  The vector-memory pipeline pays per cache access,
+// not per byte, so pieces are never split into narrower loads; loads and their wait are ONE asm statement (the
+// compiler treats asm outputs as ready when the statement ends); lanes that do not need a piece read one
+// shared address (equal addresses coalesce into a single access).  Called by ALL lanes of the wave.
+ERD void trav_fetch(const DevScene& S, bool do_step, bool tri_step, bool two, uint32_t off, float4& a, float4& b4, float4& c,
+                    float4& dd, float4& e4, float4& f4) {
+    const float4* p = S.nodes8 + (do_step ? off : 0u);
+    const float4* p34 = (do_step && (!tri_step || two)) ? p : S.nodes8;
+    const float4* p5 = (do_step && tri_step && two) ? p : S.nodes8;
+    asm volatile("global_load_dwordx4 %0, %6, off\n\t"
+                 "global_load_dwordx4 %1, %6, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %6, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %7, off offset:48\n\t"
+                 "global_load_dwordx4 %4, %7, off offset:64\n\t"
+                 "global_load_dwordx4 %5, %8, off offset:80\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b4), "=&v"(c), "=&v"(dd), "=&v"(e4), "=&v"(f4)
+                 : "v"(p), "v"(p34), "v"(p5)
+                 : "memory");
+}
+
+// phase 3.  Returns true when a shadow query found a certain occluder (the ray is then complete).
+template <bool COUNT>
+ERD bool trav_apply(Trav& T, const DevScene& S, bool tri_step, bool two, uint32_t tslot, float4 a, float4 b4, float4 c, float4 dd,
+                    float4 e4, float4 f4, unsigned& c_nodes, unsigned& c_tris) {
+    bool occluded = false;
+    const float eps_far = (S.scene_scale + (T.U < 3.0e38f ? T.U : 0.0f)) * 4e-6f;
+    const float bound = T.U + S.max_lift + eps_far;
+    if (tri_step) {
+        // Both records are tested with straight-line code (rejections folded into one predicate, exactly the
+        // comparisons of Tri::hit, reference src/Tri.h:56-77), then the interval bookkeeping runs once per record.
+        if (COUNT) c_tris += two ? 2u : 1u;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const uint32_t slot = tslot + k;
+            const F3 v0 = k == 0 ? f3(a.x, a.y, a.z) : f3(dd.x, dd.y, dd.z);
+            const F3 v1 = k == 0 ? f3(b4.x, b4.y, b4.z) : f3(e4.x, e4.y, e4.z);
+            const F3 v2 = k == 0 ? f3(c.x, c.y, c.z) : f3(f4.x, f4.y, f4.z);
+            const float lift = k == 0 ? b4.w : e4.w;
+            const float EPSILON = 0.0000001f;
+            const F3 edge1 = v1 - v0, edge2 = v2 - v0;
+            const F3 pvec = cross(T.d, edge2);
+            const float det = dot(edge1, pvec);
+            const float inv_det = 1.0f / det;
+            const F3 tvec = T.o - v0;
+            const float u = dot(tvec, pvec) * inv_det;
+            const F3 qvec = cross(tvec, edge1);
+            const float v = dot(T.d, qvec) * inv_det;
+            const float t = dot(edge2, qvec) * inv_det;
+            const bool rejected = (det > -EPSILON && det < EPSILON) || (u < 0 || u > 1) || (v < 0 || (u + v) > 1) || (t < 0);
+            const bool valid = !rejected && (k == 0 || two) && (int)slot != T.skip && !occluded;
+            const float eps = (S.scene_scale + t) * 4e-6f;
+            const float lo = t - lift - eps, hi = t + lift + eps;
+            // shadow query: certainly nearer than the self hit -> occluded; inside the interval -> ambiguous
+            const bool occl = valid && T.shadow && hi < T.limit;
+            const bool amb = valid && T.shadow && !(hi < T.limit) && lo < T.limit;
+            // closest query: survives if its lower bound does not exceed the smallest upper bound so far
+            const bool cand = valid && !T.shadow && !(lo > T.U);
+            T.U = (cand && hi < T.U) ? hi : T.U;
+            T.s0 = (cand && T.s0 >= 0 && T.lo0 > T.U) ? -1 : T.s0;
+            T.s1 = (cand && T.s1 >= 0 && T.lo1 > T.U) ? -1 : T.s1;
+            const bool want = cand || amb;
+            const bool ins0 = want && T.s0 < 0;
+            const bool ins1 = want && !ins0 && T.s1 < 0;
+            T.overflow = T.overflow || (want && !ins0 && !ins1);
+            T.s0 = ins0 ? (int)slot : T.s0;
+            T.lo0 = ins0 ? lo : T.lo0;
+            T.s1 = ins1 ? (int)slot : T.s1;
+            T.lo1 = ins1 ? lo : T.lo1;
+            occluded = occluded || occl;
+        }
+    } else {
+        if (COUNT) c_nodes++;
+        const uint32_t ebits = __builtin_bit_cast(uint32_t, a.w);
+        const float sx = __builtin_bit_cast(float, (ebits & 0xffu) << 23);
+        const float sy = __builtin_bit_cast(float, ((ebits >> 8) & 0xffu) << 23);
+        const float sz = __builtin_bit_cast(float, ((ebits >> 16) & 0xffu) << 23);
+        const uint32_t imask = ebits >> 24;
+        const uint32_t meta_w[2] = {__builtin_bit_cast(uint32_t, b4.z), __builtin_bit_cast(uint32_t, b4.w)};
+        const uint32_t qlx[2] = {__builtin_bit_cast(uint32_t, c.x), __builtin_bit_cast(uint32_t, c.y)};
+        const uint32_t qly[2] = {__builtin_bit_cast(uint32_t, c.z), __builtin_bit_cast(uint32_t, c.w)};
+        const uint32_t qlz[2] = {__builtin_bit_cast(uint32_t, dd.x), __builtin_bit_cast(uint32_t, dd.y)};
+        const uint32_t qhx[2] = {__builtin_bit_cast(uint32_t, dd.z), __builtin_bit_cast(uint32_t, dd.w)};
+        const uint32_t qhy[2] = {__builtin_bit_cast(uint32_t, e4.x), __builtin_bit_cast(uint32_t, e4.y)};
+        const uint32_t qhz[2] = {__builtin_bit_cast(uint32_t, e4.z), __builtin_bit_cast(uint32_t, e4.w)};
+        // Slab test of the eight children.  Box tests only gate the traversal, so any conservative evaluation
+        // is allowed: the entry/exit planes per axis are picked by the ray's direction sign and each plane
+        // distance is ONE fused multiply-add, t = q * (2^e * idir) + (p * idir - o * idir); its rounding error
+        // is covered by the absolute box padding of the builder (er_bvh.cpp).
+        const float Ax = sx * T.idir.x, Ay = sy * T.idir.y, Az = sz * T.idir.z;
+        const float Bx = __builtin_fmaf(a.x, T.idir.x, T.noi.x), By = __builtin_fmaf(a.y, T.idir.y, T.noi.y), Bz = __builtin_fmaf(a.z, T.idir.z, T.noi.z);
+        const bool posx = (T.oct7 & 1u) != 0, posy = (T.oct7 & 2u) != 0, posz = (T.oct7 & 4u) != 0;
+        const uint32_t nx[2] = {posx ? qlx[0] : qhx[0], posx ? qlx[1] : qhx[1]}, fx[2] = {posx ? qhx[0] : qlx[0], posx ? qhx[1] : qlx[1]};
+        const uint32_t ny[2] = {posy ? qly[0] : qhy[0], posy ? qly[1] : qhy[1]}, fy[2] = {posy ? qhy[0] : qly[0], posy ? qhy[1] : qly[1]};
+        const uint32_t nz[2] = {posz ? qlz[0] : qhz[0], posz ? qlz[1] : qhz[1]}, fz[2] = {posz ? qhz[0] : qlz[0], posz ? qhz[1] : qlz[1]};
+        uint32_t hits = 0, tmask = 0;
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) {
+            const int w = s8 >> 2, k = s8 & 3;
+            const uint32_t meta = (meta_w[w] >> (8 * k)) & 0xffu;
+            const float tnx = __builtin_fmaf(ubyte_f(nx[w], k), Ax, Bx), tfx = __builtin_fmaf(ubyte_f(fx[w], k), Ax, Bx);
+            const float tny = __builtin_fmaf(ubyte_f(ny[w], k), Ay, By), tfy = __builtin_fmaf(ubyte_f(fy[w], k), Ay, By);
+            const float tnz = __builtin_fmaf(ubyte_f(nz[w], k), Az, Bz), tfz = __builtin_fmaf(ubyte_f(fz[w], k), Az, Bz);
+            const float tmin = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+            const float tmax = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+            const bool hit = (tmin <= tmax) && (tmax >= 0.0f) && (tmin <= bound);
+            // meta: empty 0 and inner 1 have a zero triangle count, so they add no triangle bits; empty slots
+            // are not in imask, so they add no node bit either -- no branch on the child kind
+            const uint32_t leafbits = ((1u << (meta >> 5)) - 1u) << (meta & 31u);
+            hits |= hit ? (1u << s8) : 0u;
+            tmask |= hit ? leafbits : 0u;
+        }
+        // inner hits, moved from bit `slot` to bit `slot ^ oct7` (three conditional swap stages)
+        uint32_t nmask = hits & imask;
+        nmask = (T.oct7 & 1u) ? (((nmask & 0xAAu) >> 1) | ((nmask & 0x55u) << 1)) : nmask;
+        nmask = (T.oct7 & 2u) ? (((nmask & 0xCCu) >> 2) | ((nmask & 0x33u) << 2)) : nmask;
+        nmask = (T.oct7 & 4u) ? (((nmask & 0xF0u) >> 4) | ((nmask & 0x0Fu) << 4)) : nmask;
+        T.ng_base = __builtin_bit_cast(uint32_t, b4.x);
+        T.ng_bits = nmask | (imask << 8);
+        T.tg_base = __builtin_bit_cast(uint32_t, b4.y);
+        T.tg_mask = tmask;
+    }
+    return occluded;
+}
+
+// exact reference metric |Hit.position - origin| of triangle `tslot` for `ray` (inf if the ray misses it)
+ERD float exact_distance(const DevScene& S, uint32_t tslot, const Ray& ray) {
+    F3 v0, v1, v2;
+    float4 qa, qb, qc;
+    load_verts(S, tslot, v0, v1, v2, qa, qb, qc);
+    float u, v, t;
+    if (!tri_mt(v0, v1, v2, ray, u, v, t)) return __builtin_inff();
+    return candidate_distance(S, tslot, v0, v1, v2, ray, u, v, t);
+}
+
+// closest-hit result of a finished traversal: the winning slot (or -1) under the reference's exact metric
+template <bool COUNT>
+ERD int resolve_closest(const DevScene& S, int* stack2, const Ray& ray, int hslot, int h2, unsigned& c_nodes, unsigned& c_tris) {
+    if (h2 == -2) {          // more than two candidates inside one t-interval: exact scalar traversal
+        float dd;
+        return trace<COUNT, false>(S, stack2, ray, -1, __builtin_inff(), dd, c_nodes, c_tris);
+    }
+    if (h2 >= 0) {           // two candidates: the reference's strict '<' on the exact metric
+        if (exact_distance(S, (uint32_t)h2, ray) < exact_distance(S, (uint32_t)hslot, ray)) return h2;
+    }
+    return hslot;
+}
+
+// shadow query result: occ = 0 / 1 decided by the traversal, 2 = decide among ca/cb by exact metric, 3 = re-trace
+template <bool COUNT>
+ERD bool resolve_shadow(const DevScene& S, int* stack2, const Ray& sr, int self_slot, float d_self, int occ, int ca, int cb,
+                        unsigned& c_nodes, unsigned& c_tris) {
+    if (occ == 3) {
+        float dd;
+        return trace<COUNT, true>(S, stack2, sr, self_slot, d_self, dd, c_nodes, c_tris) >= 0;
+    }
+    if (occ == 2) {
+        bool nearer = exact_distance(S, (uint32_t)ca, sr) < d_self;
+        if (cb >= 0) nearer = nearer || (exact_distance(S, (uint32_t)cb, sr) < d_self);
+        return nearer;
+    }
+    return occ != 0;
+}
+
+}  // namespace erd
