@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=18.0)
     ap.add_argument("--per-step-launch", action="store_true", help="one launch per step instead of one launch for all K steps")
+    ap.add_argument("--schedule", choices=["wavefront", "fused", "megakernel"], default="wavefront")
     ap.add_argument("--sim-world", type=int, default=0, help="(diagnostic) render only rank --sim-rank's tiles of this many, no collective")
     ap.add_argument("--sim-rank", type=int, default=0)
     args = ap.parse_args()
@@ -110,8 +111,9 @@ def main():
 
     scene = scenes.soup(args.tris, args.width, args.height, seed=12345)
     shard_rank, shard_world = (args.sim_rank, args.sim_world) if (args.sim_world > 1 and world == 1) else (rank, world)
+    sched_flag = {"wavefront": 0, "fused": abi.FLAG_FUSED, "megakernel": abi.FLAG_MEGAKERNEL}[args.schedule]
     pars = render.RenderParameters(sampleTarget=256, max_bounces=args.max_bounces, device=f"hip:{local_rank}",
-                                   rank=shard_rank, world=shard_world, flags=abi.FLAG_PROFILE)
+                                   rank=shard_rank, world=shard_world, flags=abi.FLAG_PROFILE | sched_flag)
     rm = render.RenderingManager(pars)
     rm.start_rendering(scene)
     accel = rm.accel_info()
@@ -172,7 +174,7 @@ def main():
         # ---- roofline: algorithmic bytes per launch from an instrumented replay of the same samples ----
         inst = render.RenderingManager(render.RenderParameters(sampleTarget=256, max_bounces=args.max_bounces,
                                                                device=f"hip:{local_rank}", rank=shard_rank, world=shard_world,
-                                                               flags=abi.FLAG_COUNTERS))
+                                                               flags=abi.FLAG_COUNTERS | sched_flag))
         inst.start_rendering(scene)
         n_inst = min(2, args.steps)
         inst.render(n_inst)

@@ -17,7 +17,7 @@ ER_OK = 0
 ER_ERR_INVALID_ARG, ER_ERR_NO_DEVICE, ER_ERR_HIP, ER_ERR_STATE, ER_ERR_OOM = -1, -2, -3, -4, -5
 PASS_BEAUTY, PASS_DENOISE, PASS_NORMAL, PASS_TANGENT, PASS_BITANGENT, PASS_COUNT = 0, 1, 2, 3, 4, 5
 PASS_NAMES = {"beauty": 0, "denoise": 1, "normal": 2, "tangent": 3, "bitangent": 4}
-FLAG_POINT_LIGHTS, FLAG_COUNTERS, FLAG_MEGAKERNEL, FLAG_PROFILE = 1, 2, 4, 8
+FLAG_POINT_LIGHTS, FLAG_COUNTERS, FLAG_MEGAKERNEL, FLAG_PROFILE, FLAG_FUSED = 1, 2, 4, 8, 16
 
 
 class ErVec3(C.Structure):

@@ -126,7 +126,8 @@ struct ErScene {
     DevBuf<float4> d_wf4;        // 11 float4 arrays of the wavefront state, back to back
     DevBuf<uint32_t> d_wf1;      // hit, left, occluded, 4 queues, counts
     DevBuf<uint2> d_spill;
-    DevBuf<uint32_t> d_guide;
+    DevBuf<uint32_t> d_guide, d_ticket;
+    uint32_t fused_blocks = 0;
     WfState wf{};
     uint32_t trace_blocks = 0, shade_blocks = 0;
     std::vector<hipEvent_t> prof_events;   // ER_FLAG_PROFILE: e[3i], e[3i+1], e[3i+2] = before trace, between, after shade
@@ -146,7 +147,7 @@ struct ErScene {
     void release_device() {
         d_nodes.release(); d_nodes8.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_materials.release();
         d_textures.release(); d_tex_pool.release(); d_cdf.release(); d_samples.release(); d_rng.release();
-        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release();
+        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release();
         for (auto& kv : d_rank_tiles) kv.second.release();
         d_rank_tiles.clear();
         for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
@@ -401,7 +402,14 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     if ((rc = upload(s->d_owned, owned.data(), owned.size(), s->stream)) != ER_OK) return rc;
     if ((rc = upload(s->d_counters, nullptr, 1, s->stream)) != ER_OK) return rc;
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, sizeof(DevCounters), s->stream));
-    if (!(p->flags & ER_FLAG_MEGAKERNEL)) {
+    if (p->flags & ER_FLAG_FUSED) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+        s->fused_blocks = (uint32_t)prop.multiProcessorCount * 8;   // 2 waves per SIMD (register-limited)
+        if (const char* e = getenv("ER_FUSED_WAVES_PER_CU")) s->fused_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max(1, atoi(e));
+        if ((rc = upload(s->d_spill, nullptr, (size_t)s->fused_blocks * ER_BVH_MAX_DEPTH * 64, s->stream)) != ER_OK) return rc;
+        if ((rc = upload(s->d_ticket, nullptr, 1, s->stream)) != ER_OK) return rc;
+    } else if (!(p->flags & ER_FLAG_MEGAKERNEL)) {
         // wavefront path state: one slot per owned pixel lane
         size_t slots = owned.size() * 64;
         if ((rc = upload(s->d_wf4, nullptr, slots * 11, s->stream)) != ER_OK) return rc;
@@ -495,7 +503,9 @@ int er_render_samples_async(ErScene* s, uint32_t n) {
         s->timing_open = true;
     }
     const bool count = (s->params.flags & ER_FLAG_COUNTERS) != 0;
-    if (s->params.flags & ER_FLAG_MEGAKERNEL) {
+    if (s->params.flags & ER_FLAG_FUSED) {
+        er_launch_fused(s->dev, s->d_ticket.p, s->d_spill.p, n, count, s->fused_blocks, s->stream);
+    } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
         er_launch_render(s->dev, n, count, s->stream);
     } else if (n > 0) {
         // a path takes at most max_bounces ray steps plus one finalize-only step

@@ -1,0 +1,307 @@
+// er_fused.hip -- lane-asynchronous fused schedule of the per-sample path for gfx950.
+//
+// Same arithmetic per pixel as renderingKernel (reference src/kernel.cpp:477-646) and as the other two
+// schedules of this library (er_wavefront.hip, er_kernels.hip); what changes is, again, only the schedule:
+//
+//   * persistent waves; every LANE owns one pixel at a time and runs all of that pixel's samples back to back
+//     (a pixel's samples are one RNG stream); a lane that has finished its pixel takes the next unowned pixel;
+//   * there is NO barrier between bounces, neither across the GPU nor inside the wave: in every loop
+//     iteration the lanes that are tracing advance their ray by one traversal step (er_trav.h, one unified
+//     96-byte fetch for the whole wave), and the lanes whose ray has finished wait in a small "needs shading"
+//     state; the shading code runs for them as a batch as soon as enough lanes wait (or nobody is tracing);
+//   * a shadow ray is traced by the same lane before the next bounce ray (which is parked in LDS together
+//     with the two candidate contributions); its result only selects which contribution is added.
+//
+// The wavefront schedule needs one kernel pair per bounce and every launch lasts at least as long as its
+// longest ray; with few pixels per GPU (tile-sharded multi-GPU runs, the tail of a call) those floors dominate.
+// Here the critical path of a pixel is only its own rays and shading steps.
+#include "er_device.h"
+#include "er_kernels.h"
+#include "er_trav.h"
+
+using namespace erd;
+
+namespace {
+
+enum { M_IDLE = 0, M_START = 1, M_TRACE = 2, M_SHADE = 3, M_RESOLVE = 4, M_FINALIZE = 5 };
+
+__device__ __forceinline__ unsigned fwave_sum(unsigned v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+#ifndef FUSED_BATCH_MIN
+#define FUSED_BATCH_MIN 12
+#endif
+#ifndef FUSED_REFILL_MIN
+#define FUSED_REFILL_MIN 8
+#endif
+
+}  // namespace
+
+template <bool COUNT>
+__global__ __launch_bounds__(64) void er_fused_kernel(DevScene S, uint32_t* ticket, uint2* spill_base, uint32_t n_samples) {
+    __shared__ uint2 s_stack[WF_LDS_STACK * 64];
+    __shared__ float s_park[12 * 64];      // next bounce ray (o, d) + contribution if visible / if occluded
+    __shared__ float s_aov[9 * 64];        // first-bounce normal / tangent / bitangent of the current path
+    __shared__ int s_stack2[ER_STACK * 64];   // exact re-trace fallback (binary BVH)
+    const int lane = threadIdx.x;
+    uint2* stack = s_stack + lane;
+    uint2* spill = spill_base + (size_t)blockIdx.x * (ER_STACK * 64) + lane;
+    int* stack2 = s_stack2 + lane;
+    float* park = s_park + lane;
+    float* aov = s_aov + lane;
+    const uint32_t n_slots = S.owned_tile_count * 64u;
+    const size_t npx = (size_t)S.x_res * S.y_res;
+    const int hw = S.hdri_tex.width, hh = S.hdri_tex.height;
+    unsigned c_paths = 0, c_bounce = 0, c_rays = 0, c_nodes = 0, c_tris = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;
+
+    Trav T;
+    trav_begin(T, f3s(0), f3(0, 0, 1), false, -1, 0.0f);
+    int mode = M_IDLE;
+    uint32_t px = 0, py = 0, idx = 0, rs = 0, left = 0, bounce = 0;
+    F3 light = f3s(0), reduction = f3s(1);
+    bool terminal = false;   // the path is over but its last shadow ray is still being traced
+    int occ_code = 0;
+    bool exhausted = n_slots == 0 || n_samples == 0;
+
+    while (true) {
+        // ---- idle lanes take the next unowned pixels (one atomic for all of them) ----
+        unsigned long long idle = __ballot(mode == M_IDLE);
+        unsigned n_idle = __popcll(idle);
+        if (!exhausted && (n_idle >= FUSED_REFILL_MIN || n_idle == 64)) {
+            unsigned leader = __ffsll((long long)idle) - 1;
+            unsigned base = 0;
+            if (lane == (int)leader) base = atomicAdd(ticket, n_idle);
+            base = __shfl(base, leader, 64);
+            if (base + n_idle >= n_slots) exhausted = true;
+            if (mode == M_IDLE) {
+                unsigned slot = base + __popcll(idle & ((1ull << lane) - 1ull));
+                if (slot < n_slots) {
+                    uint32_t tile = S.owned_tiles[slot >> 6], l = slot & 63;
+                    px = (tile % S.tiles_x) * ER_TILE + (l & 7);
+                    py = (tile / S.tiles_x) * ER_TILE + (l >> 3);
+                    if (px < S.x_res && py < S.y_res) mode = M_START;
+                }
+            }
+        }
+        const unsigned long long want_batch = __ballot(mode == M_START || mode == M_SHADE || mode == M_RESOLVE || mode == M_FINALIZE);
+        const unsigned long long tracing = __ballot(mode == M_TRACE);
+        if (want_batch == 0 && tracing == 0) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- batch: the shading step (src/kernel.cpp:508-645) for the lanes that wait for it ----
+        if (__popcll(want_batch) >= FUSED_BATCH_MIN || tracing == 0) {
+            if (mode == M_START || mode == M_SHADE || mode == M_RESOLVE || mode == M_FINALIZE) {
+                bool fin = false, regen = false;
+                if (mode == M_START) {
+                    idx = py * S.x_res + px;
+                    rs = S.rng[idx];
+                    left = n_samples;
+                    regen = true;
+                } else if (mode == M_FINALIZE) {
+                    fin = true;
+                } else if (mode == M_RESOLVE) {
+                    // the traversal could not decide the shadow query from t-intervals: exact metric
+                    Ray sr;
+                    sr.o = T.o; sr.d = T.d;
+                    bool occ = resolve_shadow<COUNT>(S, stack2, sr, T.skip, T.limit, occ_code, T.s0, T.s1, c_nodes, c_tris);
+                    light = light + (occ ? f3(park[9 * 64], park[10 * 64], park[11 * 64]) : f3(park[6 * 64], park[7 * 64], park[8 * 64]));
+                    if (terminal) {
+                        fin = true;
+                    } else {
+                        trav_begin(T, f3(park[0], park[64], park[128]), f3(park[192], park[256], park[320]), false, -1, __builtin_inff());
+                        c_rays++;
+                        mode = M_TRACE;
+                    }
+                } else {   // M_SHADE: one iteration of the bounce loop
+                    Ray ray;
+                    ray.o = T.o; ray.d = T.d;
+                    int hslot = resolve_closest<COUNT>(S, stack2, ray, T.s0 >= 0 ? T.s0 : T.s1,
+                                                       T.overflow ? -2 : ((T.s0 >= 0 && T.s1 >= 0) ? T.s1 : -1), c_nodes, c_tris);
+                    c_bounce++;
+                    bool done = false, pending = false;
+                    if (hslot < 0) {
+                        float u, v;
+                        spherical_mapping(-1 * ray.d, u, v);
+                        light = light + reduction * tex_filtered(S, S.hdri_tex, u, v);
+                        if (COUNT) c_texels++;
+                        done = true;
+                    } else {
+                        c_shaded++;
+                        HitFull hit;
+                        full_hit(S, (uint32_t)hslot, ray, hit);
+                        const ErMaterial& mat = S.materials[hit.material];
+                        HitData hd;
+                        generate_hit_data<COUNT>(S, mat, hit, hd, c_texels);
+                        int shader = mat.albedo_shader_id;
+                        if (shader != -1) {   // asl_shade placeholder, src/shader.cpp:6-10
+                            hd.albedo = f3s(0);
+                            if (shader >= 0 && shader < 4) hd.albedo = f3(1, 1, 0);
+                        }
+                        Ray sr;
+                        sr.o = f3s(0); sr.d = f3(0, 0, 1);
+                        float d_self = __builtin_inff();
+                        if (rng_next(rs) <= hd.opacity) {
+                            F3 wo = ray.d * -1.0f;
+                            F3 N = hd.normal;
+                            c_hdri++;
+                            int count = er_cdf_search(S.hdri_cdf, hw * hh, S.hdri_guide, S.hdri_buckets, rng_next(rs));   // == HDRI::binarySearch
+                            float tcx = (float)(count % hw), tcy = (float)(count / hw);
+                            float d1 = rng_next(rs), d2 = rng_next(rs), d3 = rng_next(rs);
+                            F3 wibrdf = DisneySample(hd, wo, N, d1, d2, d3);
+                            float nu = tcx / (float)hw, nv = tcy / (float)hh;
+                            float iu, iv;
+                            inverse_transform_uv(S.hdri_tex, nu, nv, iu, iv);
+                            F3 wihdri = normalized(reverse_spherical_mapping(iu, iv)) * -1.0f;
+                            F3 hdriValue = tex_uv(S, S.hdri_tex, iu, iv);
+                            if (COUNT) c_texels += 2;
+                            F3 evalh = DisneyEval(hd, wo, N, wihdri);
+                            float hdripdf = hdri_pdf(S, ermath::f2i(iu * hw), ermath::f2i(iv * hh));
+                            float absdot = __builtin_fabsf(dot(wihdri, N));
+                            F3 c_vis = reduction * (hd.emission + hdriValue * evalh * absdot / hdripdf);
+                            if (evalh.x != 0.0f || evalh.y != 0.0f || evalh.z != 0.0f) {
+                                // shadow query needed (er_kernels.hip): occluded iff the closest hit is another triangle
+                                F3 c_occ = reduction * (hd.emission + f3s(0) * evalh * absdot / hdripdf);
+                                sr = make_ray(hd.position + N * 0.001f, wihdri);
+                                F3 v0, v1, v2;
+                                float4 qa, qb, qc4;
+                                load_verts(S, (uint32_t)hslot, v0, v1, v2, qa, qb, qc4);
+                                float su, sv, st;
+                                if (tri_mt(v0, v1, v2, sr, su, sv, st)) d_self = candidate_distance(S, (uint32_t)hslot, v0, v1, v2, sr, su, sv, st);
+                                park[6 * 64] = c_vis.x; park[7 * 64] = c_vis.y; park[8 * 64] = c_vis.z;
+                                park[9 * 64] = c_occ.x; park[10 * 64] = c_occ.y; park[11 * 64] = c_occ.z;
+                                pending = true;
+                            } else {
+                                light = light + c_vis;
+                            }
+                            float brdfpdf = DisneyPdf(hd, wo, N, wibrdf);
+                            reduction = reduction * (DisneyEval(hd, wo, N, wibrdf) * __builtin_fabsf(dot(wibrdf, N)) / brdfpdf);
+                            if (bounce == 0) {
+                                aov[0] = hd.normal.x; aov[64] = hd.normal.y; aov[128] = hd.normal.z;
+                                aov[192] = hd.tangent.x; aov[256] = hd.tangent.y; aov[320] = hd.tangent.z;
+                                aov[384] = hd.bitangent.x; aov[448] = hd.bitangent.y; aov[512] = hd.bitangent.z;
+                            }
+                            ray = make_ray(hit.position + wibrdf * 0.001f, wibrdf);
+                        } else {
+                            ray = make_ray(hit.position + ray.d * 0.001f, ray.d);
+                        }
+                        bounce++;
+                        if (bounce >= S.max_bounces) done = true;
+                        if (pending) {
+                            // trace the shadow ray first; the next bounce ray waits in LDS
+                            park[0] = ray.o.x; park[64] = ray.o.y; park[128] = ray.o.z;
+                            park[192] = ray.d.x; park[256] = ray.d.y; park[320] = ray.d.z;
+                            trav_begin(T, sr.o, sr.d, true, hslot, d_self);
+                            c_rays++;
+                            terminal = done;
+                            mode = M_TRACE;
+                        } else if (!done) {
+                            trav_begin(T, ray.o, ray.d, false, -1, __builtin_inff());
+                            c_rays++;
+                            mode = M_TRACE;
+                        }
+                    }
+                    if (done && !pending) fin = true;
+                }
+                if (fin) {
+                    // src/kernel.cpp:597-645: clamp, NaN gate, running mean over sa (starts at 1)
+                    light = f3(clampf(light.x, 0, 10), clampf(light.y, 0, 10), clampf(light.z, 0, 10));
+                    uint32_t sa = S.samples[idx];
+                    if (!(light.x != light.x) && !(light.y != light.y) && !(light.z != light.z)) {
+                        float k = ((float)sa) / ((float)(sa + 1));
+                        float inv = (float)(sa + 1);
+                        const F3 vals[4] = {light, f3(aov[0], aov[64], aov[128]), f3(aov[192], aov[256], aov[320]), f3(aov[384], aov[448], aov[512])};
+                        const int planes[4] = {ER_PASS_BEAUTY, ER_PASS_NORMAL, ER_PASS_TANGENT, ER_PASS_BITANGENT};
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            float4* pp = S.passes + (size_t)planes[q] * npx + idx;
+                            float4 p = *pp;
+                            if (sa > 0) { p.x *= k; p.y *= k; p.z *= k; }
+                            p.x += vals[q].x / inv; p.y += vals[q].y / inv; p.z += vals[q].z / inv;
+                            *pp = p;
+                        }
+                        S.samples[idx] = sa + 1;
+                    }
+                    S.rng[idx] = rs;
+                    c_paths++;
+                    left--;
+                    if (left > 0) regen = true; else mode = M_IDLE;
+                }
+                if (regen) {
+                    // src/kernel.cpp:492-493 -- five draws, left to right
+                    float c1 = rng_next(rs), c2 = rng_next(rs), c3 = rng_next(rs), c4 = rng_next(rs), c5 = rng_next(rs);
+                    Ray ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
+                    light = f3s(0);
+                    reduction = f3s(1);
+                    bounce = 0;
+                    terminal = false;
+#pragma unroll
+                    for (int q = 0; q < 9; q++) aov[q * 64] = 0.0f;
+                    trav_begin(T, ray.o, ray.d, false, -1, __builtin_inff());
+                    c_rays++;
+                    mode = M_TRACE;
+                }
+            }
+        }
+
+        // ---- one traversal step for every tracing lane ----
+        if (__ballot(mode == M_TRACE) != 0) {
+            bool finished = false, do_step = false, tri_step = false, two = false;
+            uint32_t tslot = 0, off = 0;
+            if (mode == M_TRACE) do_step = trav_choose(T, S, stack, spill, finished, tri_step, two, tslot, off);
+            float4 a, b4, c, dd, e4, f4;
+            trav_fetch(S, do_step, tri_step, two, off, a, b4, c, dd, e4, f4);
+            if (mode == M_TRACE) {
+                int code = -1;
+                if (do_step) {
+                    if (trav_apply<COUNT>(T, S, tri_step, two, tslot, a, b4, c, dd, e4, f4, c_nodes, c_tris)) { finished = true; code = 1; }
+                } else if (T.shadow) {
+                    code = T.overflow ? 3 : (T.s0 >= 0 ? 2 : 0);
+                }
+                if (finished) {
+                    if (!T.shadow) {
+                        mode = M_SHADE;
+                    } else if (code <= 1) {
+                        // the shadow query's outcome only selects which precomputed contribution is added
+                        light = light + (code ? f3(park[9 * 64], park[10 * 64], park[11 * 64]) : f3(park[6 * 64], park[7 * 64], park[8 * 64]));
+                        if (terminal) {
+                            mode = M_FINALIZE;
+                        } else {
+                            trav_begin(T, f3(park[0], park[64], park[128]), f3(park[192], park[256], park[320]), false, -1, __builtin_inff());
+                            c_rays++;
+                        }
+                    } else {
+                        occ_code = code;
+                        mode = M_RESOLVE;
+                    }
+                }
+            }
+        }
+    }
+    unsigned t0 = fwave_sum(c_paths), t1 = fwave_sum(c_bounce), t2 = fwave_sum(c_rays), t3 = fwave_sum(c_shaded), t4 = fwave_sum(c_hdri);
+    unsigned t5 = 0, t6 = 0, t7 = 0;
+    if (COUNT) { t5 = fwave_sum(c_nodes); t6 = fwave_sum(c_tris); t7 = fwave_sum(c_texels); }
+    if (lane == 0 && (t0 | t1 | t2)) {
+        atomicAdd(&S.counters->paths, (unsigned long long)t0);
+        atomicAdd(&S.counters->bounce_samples, (unsigned long long)t1);
+        atomicAdd(&S.counters->rays, (unsigned long long)t2);
+        atomicAdd(&S.counters->shaded_hits, (unsigned long long)t3);
+        atomicAdd(&S.counters->hdri_samples, (unsigned long long)t4);
+        if (COUNT) {
+            atomicAdd(&S.counters->node_visits, (unsigned long long)t5);
+            atomicAdd(&S.counters->tri_tests, (unsigned long long)t6);
+            atomicAdd(&S.counters->texel_fetches, (unsigned long long)t7);
+        }
+    }
+}
+
+void er_launch_fused(const DevScene& S, uint32_t* ticket, void* spill, uint32_t n_samples, bool count, uint32_t blocks, hipStream_t stream) {
+    if (S.owned_tile_count == 0 || n_samples == 0) return;
+    (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+    if (count) hipLaunchKernelGGL(er_fused_kernel<true>, dim3(blocks), dim3(64), 0, stream, S, ticket, (uint2*)spill, n_samples);
+    else hipLaunchKernelGGL(er_fused_kernel<false>, dim3(blocks), dim3(64), 0, stream, S, ticket, (uint2*)spill, n_samples);
+}

@@ -113,6 +113,7 @@ typedef struct ErSceneDesc {
 #define ER_FLAG_POINT_LIGHTS 1u   /* extension, default off = reference behaviour */
 #define ER_FLAG_COUNTERS     2u   /* count node visits / triangle tests (slower kernel variant) */
 #define ER_FLAG_MEGAKERNEL   4u   /* one fused kernel per call instead of the wavefront schedule (same results) */
+#define ER_FLAG_FUSED        16u  /* lane-asynchronous fused schedule (no per-bounce barrier; same results) */
 #define ER_FLAG_PROFILE      8u   /* bracket every trace / shade launch with HIP events (see er_get_profile) */
 
 /* reference RenderParameters (src/kernel.h:51-69) + what the MI355X build adds. */
