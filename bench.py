@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=18.0)
     ap.add_argument("--per-step-launch", action="store_true", help="one launch per step instead of one launch for all K steps")
-    ap.add_argument("--schedule", choices=["wavefront", "fused", "megakernel"], default="wavefront")
+    ap.add_argument("--schedule", choices=["auto", "wavefront", "fused", "megakernel"], default="auto")
     ap.add_argument("--sim-world", type=int, default=0, help="(diagnostic) render only rank --sim-rank's tiles of this many, no collective")
     ap.add_argument("--sim-rank", type=int, default=0)
     args = ap.parse_args()
@@ -111,7 +111,7 @@ def main():
 
     scene = scenes.soup(args.tris, args.width, args.height, seed=12345)
     shard_rank, shard_world = (args.sim_rank, args.sim_world) if (args.sim_world > 1 and world == 1) else (rank, world)
-    sched_flag = {"wavefront": 0, "fused": abi.FLAG_FUSED, "megakernel": abi.FLAG_MEGAKERNEL}[args.schedule]
+    sched_flag = {"auto": 0, "wavefront": abi.FLAG_WAVEFRONT, "fused": abi.FLAG_FUSED, "megakernel": abi.FLAG_MEGAKERNEL}[args.schedule]
     pars = render.RenderParameters(sampleTarget=256, max_bounces=args.max_bounces, device=f"hip:{local_rank}",
                                    rank=shard_rank, world=shard_world, flags=abi.FLAG_PROFILE | sched_flag)
     rm = render.RenderingManager(pars)
@@ -188,6 +188,10 @@ def main():
         path_b = path_bytes(ci, hdri_texels) / max(1, ci["bounce_samples"]) * my_samples
         t_launches = max(1, prof["trace_launches"])
         trace_ms_avg = prof["trace_ms"] / t_launches
+        sched = {abi.FLAG_WAVEFRONT: "wavefront", abi.FLAG_FUSED: "fused", abi.FLAG_MEGAKERNEL: "megakernel"}.get(prof["schedule"], "?")
+        kernel_name = {"wavefront": "er_wf_trace", "fused": "er_fused_kernel", "megakernel": "er_render_kernel"}.get(sched, "?")
+        if sched != "wavefront":
+            trace_b = path_b      # the single kernel of these schedules does the whole path
         achieved = (trace_b / t_launches) / (trace_ms_avg * 1e-3) / 1e9 if trace_ms_avg > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes
@@ -204,12 +208,13 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C2: {args.tris}-triangle random soup + 2048x1024 sky HDRI, {args.width}x{args.height}, "
                                    f"max_bounces {args.max_bounces}, 1 step = 1 spp pass (config total 256 spp), seed 12345",
-                       "sharding": f"8x8 pixel tiles, (tx+ty) % {world}", "calls_in_timed_region": launches},
+                       "sharding": f"8x8 pixel tiles, (tx+ty) % {shard_world}", "calls_in_timed_region": launches,
+                       "schedule": sched},
             "paths_per_s": round(paths / elapsed, 1), "rays_per_s": round(rays / elapsed, 1),
             "mean_path_length": round(samples / max(1, paths), 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "er_wf_trace", "launches": prof["trace_launches"],
+                         "kernel": kernel_name, "launches": prof["trace_launches"],
                          "avg_launch_ms": round(trace_ms_avg, 5), "algorithmic_bytes_per_launch": round(trace_b / t_launches, 1),
                          "trace_ms_total": round(prof["trace_ms"], 3), "shade_ms_total": round(prof["shade_ms"], 3),
                          "whole_path_GBps": round(path_b / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else None,

@@ -402,14 +402,22 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     if ((rc = upload(s->d_owned, owned.data(), owned.size(), s->stream)) != ER_OK) return rc;
     if ((rc = upload(s->d_counters, nullptr, 1, s->stream)) != ER_OK) return rc;
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, sizeof(DevCounters), s->stream));
-    if (p->flags & ER_FLAG_FUSED) {
+    // schedule: forced by a flag, else by how many pixels this rank owns (see eleven_hip.h)
+    {
+        const uint32_t forced = p->flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT);
+        uint32_t sched = forced;
+        if (forced == 0) sched = (owned.size() * 64 > 1200000u) ? ER_FLAG_WAVEFRONT : ER_FLAG_FUSED;
+        else if (forced & (forced - 1)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: more than one schedule flag");
+        s->params.flags = (s->params.flags & ~(uint32_t)(ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT)) | sched;
+    }
+    if (s->params.flags & ER_FLAG_FUSED) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         s->fused_blocks = (uint32_t)prop.multiProcessorCount * 8;   // 2 waves per SIMD (register-limited)
         if (const char* e = getenv("ER_FUSED_WAVES_PER_CU")) s->fused_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max(1, atoi(e));
         if ((rc = upload(s->d_spill, nullptr, (size_t)s->fused_blocks * ER_BVH_MAX_DEPTH * 64, s->stream)) != ER_OK) return rc;
         if ((rc = upload(s->d_ticket, nullptr, 1, s->stream)) != ER_OK) return rc;
-    } else if (!(p->flags & ER_FLAG_MEGAKERNEL)) {
+    } else if (s->params.flags & ER_FLAG_WAVEFRONT) {
         // wavefront path state: one slot per owned pixel lane
         size_t slots = owned.size() * 64;
         if ((rc = upload(s->d_wf4, nullptr, slots * 11, s->stream)) != ER_OK) return rc;
@@ -503,11 +511,25 @@ int er_render_samples_async(ErScene* s, uint32_t n) {
         s->timing_open = true;
     }
     const bool count = (s->params.flags & ER_FLAG_COUNTERS) != 0;
+    const bool single = (s->params.flags & (ER_FLAG_FUSED | ER_FLAG_MEGAKERNEL)) != 0;
+    if (single && (s->params.flags & ER_FLAG_PROFILE) && n > 0) {
+        while (s->prof_events.size() < s->prof_used + 3) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            s->prof_events.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(s->prof_events[s->prof_used++], s->stream));
+    }
     if (s->params.flags & ER_FLAG_FUSED) {
         er_launch_fused(s->dev, s->d_ticket.p, s->d_spill.p, n, count, s->fused_blocks, s->stream);
     } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
         er_launch_render(s->dev, n, count, s->stream);
-    } else if (n > 0) {
+    }
+    if (single && (s->params.flags & ER_FLAG_PROFILE) && n > 0) {
+        HIP_TRY(hipEventRecord(s->prof_events[s->prof_used++], s->stream));
+        HIP_TRY(hipEventRecord(s->prof_events[s->prof_used++], s->stream));   // (trace, shade) triple: shade = 0
+    }
+    if (!single && n > 0) {
         // a path takes at most max_bounces ray steps plus one finalize-only step
         const uint32_t iters = n * (s->params.max_bounces + 1);
         er_launch_wf_begin(s->dev, s->wf, n, s->stream);
@@ -547,6 +569,7 @@ int er_wait(ErScene* s, float* elapsed_ms) {
     }
     if (elapsed_ms) *elapsed_ms = ms;
     s->profile = ErProfile{};
+    s->profile.schedule = s->params.flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT);
     for (size_t i = 0; i + 2 < s->prof_used; i += 3) {
         float a = 0, b = 0;
         HIP_TRY(hipEventElapsedTime(&a, s->prof_events[i], s->prof_events[i + 1]));

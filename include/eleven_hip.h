@@ -112,8 +112,12 @@ typedef struct ErSceneDesc {
 
 #define ER_FLAG_POINT_LIGHTS 1u   /* extension, default off = reference behaviour */
 #define ER_FLAG_COUNTERS     2u   /* count node visits / triangle tests (slower kernel variant) */
-#define ER_FLAG_MEGAKERNEL   4u   /* one fused kernel per call instead of the wavefront schedule (same results) */
-#define ER_FLAG_FUSED        16u  /* lane-asynchronous fused schedule (no per-bounce barrier; same results) */
+/* Schedule selection (every schedule computes bit-identical results).  Default: automatic -- the wavefront schedule
+ * when this rank owns many pixels (> 1.2M), the lane-asynchronous fused schedule otherwise (few pixels per GPU make
+ * the per-bounce launches of the wavefront latency-bound).  The flags force one. */
+#define ER_FLAG_MEGAKERNEL   4u   /* v0: one wave per 8x8 tile, wave-synchronous bounce loop over the binary BVH */
+#define ER_FLAG_FUSED        16u  /* persistent waves, lane-asynchronous: trace steps + batched shading, no barrier */
+#define ER_FLAG_WAVEFRONT    32u  /* one trace + one shade launch per bounce over compacted ray queues */
 #define ER_FLAG_PROFILE      8u   /* bracket every trace / shade launch with HIP events (see er_get_profile) */
 
 /* reference RenderParameters (src/kernel.h:51-69) + what the MI355X build adds. */
@@ -196,6 +200,8 @@ int er_get_counters(ErScene* scene, ErCounters* out);
 typedef struct ErProfile {
     float trace_ms, shade_ms;          /* summed over launches */
     uint32_t trace_launches, shade_launches;
+    uint32_t schedule;                 /* ER_FLAG_WAVEFRONT / ER_FLAG_FUSED / ER_FLAG_MEGAKERNEL actually in use; for the
+                                          two single-kernel schedules trace_ms is that kernel's time and shade_ms is 0 */
 } ErProfile;
 int er_get_profile(ErScene* scene, ErProfile* out);
 

@@ -120,7 +120,7 @@ def test_gpu_reproduces_golden_fixtures(name):
 def test_megakernel_schedule_equals_wavefront_schedule():
     """ER_FLAG_MEGAKERNEL (one fused kernel) and the default wavefront schedule are the same arithmetic."""
     sc = scenes.soup(3000, 96, 64, seed=11, hdri_size=(64, 32))
-    a = gpu_render(sc, 5, max_bounces=8)
+    a = gpu_render(sc, 5, max_bounces=8, flags=abi.FLAG_WAVEFRONT)
     b = gpu_render(sc, 5, max_bounces=8, flags=abi.FLAG_MEGAKERNEL)
     for p in ("beauty", "normal", "tangent", "bitangent"):
         assert (a[p].view(np.uint32) == b[p].view(np.uint32)).all()
@@ -204,8 +204,10 @@ def test_full_size_properties():
     assert (a["samples"] == 4).mean() > 0.999          # NaN-gated samples are the only exceptions
     assert np.isfinite(a["beauty"]).all() and a["beauty"][..., :3].min() >= 0 and a["beauty"][..., :3].max() <= 10
     assert a["info"] == 4
-    w = gpu_render(sc, 3, max_bounces=8, rank=7, world=64)
+    w = gpu_render(sc, 3, max_bounces=8, rank=7, world=64, flags=abi.FLAG_WAVEFRONT)
     m = gpu_render(sc, 3, max_bounces=8, rank=7, world=64, flags=abi.FLAG_MEGAKERNEL)
+    f = gpu_render(sc, 3, max_bounces=8, rank=7, world=64, flags=abi.FLAG_FUSED)
+    assert (w["beauty"].view(np.uint32) == f["beauty"].view(np.uint32)).all()
     assert (w["beauty"].view(np.uint32) == m["beauty"].view(np.uint32)).all()
     assert w["counters"]["bounce_samples"] == m["counters"]["bounce_samples"]
     # the sharded window agrees with the full render on the pixels it owns
@@ -224,7 +226,7 @@ def test_fused_schedule_equals_wavefront_schedule(scene_kind):
         sc = scenes.blob_instances(n_instances=40, tris_per_blob=300, x_res=96, y_res=72, grid=(5, 4, 2), spacing=0.45)
     else:
         sc = scenes.cornell(100, 60)
-    a = gpu_render(sc, 7, max_bounces=8)
+    a = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_WAVEFRONT)
     b = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_FUSED)
     c = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_FUSED, chunks=[3, 4])
     for p in ("beauty", "normal", "tangent", "bitangent"):
