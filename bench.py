@@ -102,10 +102,19 @@ def main():
     from elevenrender_amd import abi, render, scenes
 
     dist = None
+    # ER_BENCH_REHEARSAL=1: several ranks share GPU 0 and talk over gloo (RCCL refuses two ranks on one GPU); used to
+    # rehearse the N>1 control flow on a one-GPU box.  The driver's real runs use one GPU per rank and RCCL.
+    rehearsal = os.environ.get("ER_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
+    coll_dev = "cpu" if rehearsal else "cuda"
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
 
@@ -145,10 +154,10 @@ def main():
     paths = c_after["paths"] - c_before["paths"]
     rays = c_after["rays"] - c_before["rays"]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([samples, paths, rays], dtype=torch.float64, device="cuda")
+        tot = torch.tensor([samples, paths, rays], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         samples, paths, rays = (int(v) for v in tot.tolist())
 
@@ -159,8 +168,12 @@ def main():
         rows = [rm.owned_count(r) for r in range(world)]
         mine = torch.zeros((rows[rank], 4), dtype=torch.float32, device="cuda")
         rm.pack_owned(abi.PASS_BEAUTY, mine.data_ptr())
-        erdist.gather_plane(dist, rank, world, mine, max(rows),
-                            lambda r, t: rm.unpack_owned(abi.PASS_BEAUTY, r, t.contiguous().data_ptr()))
+
+        def unpack(r, t):
+            t = t.contiguous().cuda()
+            torch.cuda.synchronize()
+            rm.unpack_owned(abi.PASS_BEAUTY, r, t.data_ptr())
+        erdist.gather_plane(dist, rank, world, mine.to(coll_dev), max(rows), unpack)
         torch.cuda.synchronize()
     beauty_mean = None
     if rank == 0:
