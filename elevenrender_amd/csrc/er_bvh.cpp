@@ -370,14 +370,13 @@ static void collapse_bvh8(ErBvhBuild* out) {
             }
             if (!c.as_leaf) {
                 nd.imask |= (uint8_t)(1u << s8);
-                nd.meta[s8] = 1;
                 uint32_t idx = (uint32_t)out->nodes8.size();
                 out->nodes8.emplace_back();
                 queue.push_back(Work{idx, c.ref, w.depth + 1});
             } else {
                 uint32_t first = c.ref < 0 ? leaf_first(c.ref) : dp[c.ref].first;
                 uint32_t count = c.ref < 0 ? leaf_count(c.ref) : dp[c.ref].count;
-                nd.meta[s8] = (uint8_t)((count << 5) | tri_off);
+                nd.tri_present |= ((1u << count) - 1u) << (2 * s8);
                 uint32_t new_first = (uint32_t)new_order.size();
                 for (uint32_t i = 0; i < count; i++) new_order.push_back(first + i);
                 tri_off += count;

@@ -57,11 +57,13 @@ struct ErNode8 {            // 80 bytes = five 16-byte loads
     uint8_t imask;          // bit s: slot s holds an inner node
     uint32_t child_base;
     uint32_t tri_base;
-    uint8_t meta[8];        // 0 = empty; inner: 1; leaf: (count << 5) | offset   (count 1..4, offset < 32)
+    uint32_t tri_present;   // bit 2*s + j: slot s is a leaf with more than j triangles (leaves hold <= 2)
+    uint32_t reserved;      // the node's triangles are stored compactly in bit order from tri_base
     uint8_t qlo[3][8];
     uint8_t qhi[3][8];
 };
 static_assert(sizeof(ErNode8) == 80, "wide node must be 80 bytes");
+static_assert(ER_BVH_LEAF_MAX <= 2, "ErNode8::tri_present has two bits per child slot");
 
 struct ErBvhBuild {
     std::vector<ErNode8> nodes8;         // 8-wide compressed tree over the same triangle order

@@ -2,9 +2,9 @@
 // (er_wavefront.hip) and the fused lane-asynchronous kernel (er_fused.hip).
 //
 // A lane owns one ray at a time and advances it by ONE step per call sequence
-//     trav_choose  (pop if nothing is pending; pick a NODE step or a TRIANGLE step and its address)
-//     trav_fetch   (up to 96 bytes from that address, whole 16-byte pieces)
-//     trav_apply   (decode + 8 box tests, or Moller-Trumbore on one/two records + interval bookkeeping)
+//     trav_choose  (pick the step's TRIANGLE part and/or NODE part and their addresses; pop if nothing is pending)
+//     trav_fetch   (80 bytes of node + up to 96 bytes of triangle records, whole 16-byte pieces)
+//     trav_apply   (Moller-Trumbore on one/two records + interval bookkeeping, then decode + 8 box tests)
 // Traversal state (after Ylitie, Karras, Laine 2017): the current NODE GROUP (first-child index + mask of hit
 // inner children, stored at bit `slot ^ octant` so the highest set bit is the nearest child) and the current
 // TRIANGLE GROUP (first slot + mask).  Only node groups are pushed, at most one per level, so the stack is
@@ -28,11 +28,13 @@ struct Trav {
     float U, limit, lo0, lo1;        // closest: smallest upper bound so far; shadow: exact distance of the self hit
     int s0, s1, skip;                // surviving candidates; slot to ignore (shadow query: the triangle the ray leaves)
     uint32_t ng_base, ng_bits;       // node group: first child index; hit mask (bits 0-7, octant order) | imask << 8
-    uint32_t tg_base, tg_mask;       // triangle group: first slot; mask of slots still to test
+    uint32_t tg_base, tg_mask;       // triangle group: first slot; bits 0-15 still to test | the node's tri_present << 16
     uint32_t oct7;
     int sp;
     bool overflow, shadow;
 };
+
+typedef float V2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
 
@@ -57,91 +59,127 @@ ERD void trav_begin(Trav& T, F3 o, F3 d, bool shadow, int skip, float limit) {
     T.tg_base = 0; T.tg_mask = 0;
 }
 
-// phase 1.  Returns true if the lane takes a step this iteration; `finished` = the ray is complete (stack empty).
-ERD bool trav_choose(Trav& T, const DevScene& S, uint2* stack, uint2* spill, bool& finished, bool& tri_step, bool& two,
-                     uint32_t& tslot, uint32_t& off) {
-    finished = false; tri_step = false; two = false; tslot = 0; off = 0;
-    if (T.tg_mask == 0 && (T.ng_bits & 0xffu) == 0) {
-        if (T.sp == 0) { finished = true; return false; }
-        T.sp--;
-        uint2 g = T.sp < WF_LDS_STACK ? stack[T.sp * 64] : spill[(T.sp - WF_LDS_STACK) * 64];
-        T.ng_base = g.x;
-        T.ng_bits = g.y;
+// What one lane does in one step: a NODE part (decode one compressed node, test its eight children), a
+// TRIANGLE part (one or two records of the pending triangle group), or both.  The trace kernels are bound by
+// vector-ALU issue, and a wave pays for the node block and the triangle block whenever ANY of its lanes needs
+// them -- so a lane that has both kinds of work pending does both in the same step instead of taking turns.
+struct TravStep {
+    bool node, tri, two;
+    uint32_t tslot, noff, toff;      // first triangle slot; piece offsets (16-byte units from S.nodes8)
+};
+
+// phase 1.  Returns true if the lane takes a step this iteration; false = the ray is complete (nothing pending).
+// The triangle part drains the current triangle group; the node part (which replaces that group) runs as soon
+// as this step's triangle part empties it.
+ERD bool trav_choose(Trav& T, const DevScene& S, uint2* stack, uint2* spill, TravStep& st) {
+    st.node = false; st.two = false; st.tslot = 0; st.noff = 0; st.toff = 0;
+    st.tri = (T.tg_mask & 0xffffu) != 0;
+    if (st.tri) {
+        // pending bit i is triangle number popcount(present bits below i) of the group; a second pending
+        // triangle rides along when it is the very next record in memory
+        const uint32_t m = T.tg_mask & 0xffffu, present = T.tg_mask >> 16;
+        const unsigned i = __ffs(m) - 1;
+        const uint32_t rest = m & (m - 1u);
+        const unsigned j = __ffs(rest | 0x10000u) - 1;
+        st.two = rest != 0 && (present & ((1u << j) - 1u) & ~((2u << i) - 1u)) == 0;
+        T.tg_mask = (T.tg_mask & 0xffff0000u) | (st.two ? (rest & (rest - 1u)) : rest);
+        st.tslot = T.tg_base + __popc(present & ((1u << i) - 1u));
+        st.toff = S.tri_base_pieces + st.tslot * 3u;
     }
-    tri_step = T.tg_mask != 0;
-    if (tri_step) {
-        unsigned i = __ffs(T.tg_mask) - 1;
-        two = ((T.tg_mask >> i) & 2u) != 0;
-        T.tg_mask &= ~((two ? 3u : 1u) << i);
-        tslot = T.tg_base + i;
-        off = S.tri_base_pieces + tslot * 3u;
-    } else {
-        uint32_t nmask = T.ng_bits & 0xffu, imask = (T.ng_bits >> 8) & 0xffu;
-        unsigned b = 31 - __clz(nmask);
-        nmask &= ~(1u << b);
-        unsigned s8 = b ^ T.oct7;
-        uint32_t child = T.ng_base + __popc(imask & ((1u << s8) - 1u));
-        if (nmask) {                       // siblings still to visit: one stack entry for the whole group
-            uint2 g = make_uint2(T.ng_base, nmask | (imask << 8));
-            if (T.sp < WF_LDS_STACK) stack[T.sp * 64] = g; else spill[(T.sp - WF_LDS_STACK) * 64] = g;
-            T.sp++;
+    if ((T.tg_mask & 0xffffu) == 0) {
+        if ((T.ng_bits & 0xffu) == 0 && T.sp > 0) {
+            T.sp--;
+            uint2 g = T.sp < WF_LDS_STACK ? stack[T.sp * 64] : spill[(T.sp - WF_LDS_STACK) * 64];
+            T.ng_base = g.x;
+            T.ng_bits = g.y;
         }
-        T.ng_bits = 0;
-        off = child * 5u;
+        if ((T.ng_bits & 0xffu) != 0) {
+            st.node = true;
+            uint32_t nmask = T.ng_bits & 0xffu, imask = (T.ng_bits >> 8) & 0xffu;
+            unsigned b = 31 - __clz(nmask);
+            nmask &= ~(1u << b);
+            unsigned s8 = b ^ T.oct7;
+            uint32_t child = T.ng_base + __popc(imask & ((1u << s8) - 1u));
+            if (nmask) {                       // siblings still to visit: one stack entry for the whole group
+                uint2 g = make_uint2(T.ng_base, nmask | (imask << 8));
+                if (T.sp < WF_LDS_STACK) stack[T.sp * 64] = g; else spill[(T.sp - WF_LDS_STACK) * 64] = g;
+                T.sp++;
+            }
+            T.ng_bits = 0;
+            st.noff = child * 5u;
+        }
     }
-    return true;
+    return st.tri || st.node;
 }
 
-// phase 2: per-lane fetch of up to six whole dwordx4 pieces.  The vector-memory pipeline pays per cache access,
-// not per byte, so pieces are never split into narrower loads; loads and their wait are ONE asm statement (the
-// compiler treats asm outputs as ready when the statement ends); lanes that do not need a piece read one
-// shared address (equal addresses coalesce into a single access).  Called by ALL lanes of the wave.
-ERD void trav_fetch(const DevScene& S, bool do_step, bool tri_step, bool two, uint32_t off, float4& a, float4& b4, float4& c,
-                    float4& dd, float4& e4, float4& f4) {
-    const float4* p = S.nodes8 + (do_step ? off : 0u);
-    const float4* p34 = (do_step && (!tri_step || two)) ? p : S.nodes8;
-    const float4* p5 = (do_step && tri_step && two) ? p : S.nodes8;
-    asm volatile("global_load_dwordx4 %0, %6, off\n\t"
-                 "global_load_dwordx4 %1, %6, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %6, off offset:32\n\t"
-                 "global_load_dwordx4 %3, %7, off offset:48\n\t"
-                 "global_load_dwordx4 %4, %7, off offset:64\n\t"
-                 "global_load_dwordx4 %5, %8, off offset:80\n\t"
+// phase 2: per-lane fetch of whole dwordx4 pieces: five for the node part, three or six for the triangle part.
+// The vector-memory pipeline pays per cache access, not per byte, so pieces are never split into narrower
+// loads; loads and their wait are ONE asm statement (the compiler treats asm outputs as ready when the
+// statement ends); lanes that do not need a piece read one shared address (equal addresses coalesce into a
+// single access).  Called by ALL lanes of the wave.
+struct TravData {
+    float4 n0, n1, n2, n3, n4;       // node: origin+exponents+imask | bases+meta | quantised planes
+    float4 a, b4, c, dd, e4, f4;     // triangle records: v0|v1|v2 of the first, then of the second
+};
+
+ERD void trav_fetch(const DevScene& S, const TravStep& st, TravData& D) {
+    const float4* pn = S.nodes8 + (st.node ? st.noff : 0u);
+    const float4* pt = S.nodes8 + (st.tri ? st.toff : 0u);
+    const float4* pt2 = (st.tri && st.two) ? pt : S.nodes8;
+    asm volatile("global_load_dwordx4 %0, %11, off\n\t"
+                 "global_load_dwordx4 %1, %11, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %11, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %11, off offset:48\n\t"
+                 "global_load_dwordx4 %4, %11, off offset:64\n\t"
+                 "global_load_dwordx4 %5, %12, off\n\t"
+                 "global_load_dwordx4 %6, %12, off offset:16\n\t"
+                 "global_load_dwordx4 %7, %12, off offset:32\n\t"
+                 "global_load_dwordx4 %8, %13, off offset:48\n\t"
+                 "global_load_dwordx4 %9, %13, off offset:64\n\t"
+                 "global_load_dwordx4 %10, %13, off offset:80\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b4), "=&v"(c), "=&v"(dd), "=&v"(e4), "=&v"(f4)
-                 : "v"(p), "v"(p34), "v"(p5)
+                 : "=&v"(D.n0), "=&v"(D.n1), "=&v"(D.n2), "=&v"(D.n3), "=&v"(D.n4), "=&v"(D.a), "=&v"(D.b4), "=&v"(D.c), "=&v"(D.dd),
+                   "=&v"(D.e4), "=&v"(D.f4)
+                 : "v"(pn), "v"(pt), "v"(pt2)
                  : "memory");
 }
 
 // phase 3.  Returns true when a shadow query found a certain occluder (the ray is then complete).
 template <bool COUNT>
-ERD bool trav_apply(Trav& T, const DevScene& S, bool tri_step, bool two, uint32_t tslot, float4 a, float4 b4, float4 c, float4 dd,
-                    float4 e4, float4 f4, unsigned& c_nodes, unsigned& c_tris) {
+ERD bool trav_apply(Trav& T, const DevScene& S, const TravStep& st, const TravData& D, unsigned& c_nodes, unsigned& c_tris) {
     bool occluded = false;
-    const float eps_far = (S.scene_scale + (T.U < 3.0e38f ? T.U : 0.0f)) * 4e-6f;
-    const float bound = T.U + S.max_lift + eps_far;
-    if (tri_step) {
+    if (st.tri) {
+        const bool two = st.two;
+        const uint32_t tslot = st.tslot;
+        const float4 a = D.a, b4 = D.b4, c = D.c, dd = D.dd, e4 = D.e4, f4 = D.f4;
         // Both records are tested with straight-line code (rejections folded into one predicate, exactly the
         // comparisons of Tri::hit, reference src/Tri.h:56-77), then the interval bookkeeping runs once per record.
         if (COUNT) c_tris += two ? 2u : 1u;
+        // the two records go through Moller-Trumbore side by side as the halves of packed f32 operations
+        // (v_pk_mul_f32 / v_pk_add_f32 round each half exactly like the scalar instruction, and the expression
+        // order is that of Tri::hit, so t, u, v are the reference's bits)
+        const V2 dx = {T.d.x, T.d.x}, dy = {T.d.y, T.d.y}, dz = {T.d.z, T.d.z};
+        const V2 ox = {T.o.x, T.o.x}, oy = {T.o.y, T.o.y}, oz = {T.o.z, T.o.z};
+        const V2 v0x = {a.x, dd.x}, v0y = {a.y, dd.y}, v0z = {a.z, dd.z};
+        const V2 e1x = (V2){b4.x, e4.x} - v0x, e1y = (V2){b4.y, e4.y} - v0y, e1z = (V2){b4.z, e4.z} - v0z;
+        const V2 e2x = (V2){c.x, f4.x} - v0x, e2y = (V2){c.y, f4.y} - v0y, e2z = (V2){c.z, f4.z} - v0z;
+        const V2 px = dy * e2z - dz * e2y, py = -(dx * e2z - dz * e2x), pz = dx * e2y - dy * e2x;        // cross(d, edge2)
+        const V2 det2 = e1x * px + e1y * py + e1z * pz;
+        const V2 inv2 = {1.0f / det2.x, 1.0f / det2.y};
+        const V2 tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+        const V2 u2 = (tx * px + ty * py + tz * pz) * inv2;
+        const V2 qx = ty * e1z - tz * e1y, qy = -(tx * e1z - tz * e1x), qz = tx * e1y - ty * e1x;        // cross(tvec, edge1)
+        const V2 v2_ = (dx * qx + dy * qy + dz * qz) * inv2;
+        const V2 t2 = (e2x * qx + e2y * qy + e2z * qz) * inv2;
+        const V2 uv2 = u2 + v2_;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const uint32_t slot = tslot + k;
-            const F3 v0 = k == 0 ? f3(a.x, a.y, a.z) : f3(dd.x, dd.y, dd.z);
-            const F3 v1 = k == 0 ? f3(b4.x, b4.y, b4.z) : f3(e4.x, e4.y, e4.z);
-            const F3 v2 = k == 0 ? f3(c.x, c.y, c.z) : f3(f4.x, f4.y, f4.z);
             const float lift = k == 0 ? b4.w : e4.w;
             const float EPSILON = 0.0000001f;
-            const F3 edge1 = v1 - v0, edge2 = v2 - v0;
-            const F3 pvec = cross(T.d, edge2);
-            const float det = dot(edge1, pvec);
-            const float inv_det = 1.0f / det;
-            const F3 tvec = T.o - v0;
-            const float u = dot(tvec, pvec) * inv_det;
-            const F3 qvec = cross(tvec, edge1);
-            const float v = dot(T.d, qvec) * inv_det;
-            const float t = dot(edge2, qvec) * inv_det;
-            const bool rejected = (det > -EPSILON && det < EPSILON) || (u < 0 || u > 1) || (v < 0 || (u + v) > 1) || (t < 0);
+            const float det = k == 0 ? det2.x : det2.y, u = k == 0 ? u2.x : u2.y, v = k == 0 ? v2_.x : v2_.y, t = k == 0 ? t2.x : t2.y;
+            const float upv = k == 0 ? uv2.x : uv2.y;
+            const bool rejected = (det > -EPSILON && det < EPSILON) || (u < 0 || u > 1) || (v < 0 || upv > 1) || (t < 0);
             const bool valid = !rejected && (k == 0 || two) && (int)slot != T.skip && !occluded;
             const float eps = (S.scene_scale + t) * 4e-6f;
             const float lo = t - lift - eps, hi = t + lift + eps;
@@ -163,14 +201,19 @@ ERD bool trav_apply(Trav& T, const DevScene& S, bool tri_step, bool two, uint32_
             T.lo1 = ins1 ? lo : T.lo1;
             occluded = occluded || occl;
         }
-    } else {
+    }
+    if (st.node && !occluded) {
+        // the pruning bound, after this step's triangles have tightened U
+        const float eps_far = (S.scene_scale + (T.U < 3.0e38f ? T.U : 0.0f)) * 4e-6f;
+        const float bound = T.U + S.max_lift + eps_far;
+        const float4 a = D.n0, b4 = D.n1, c = D.n2, dd = D.n3, e4 = D.n4;
         if (COUNT) c_nodes++;
         const uint32_t ebits = __builtin_bit_cast(uint32_t, a.w);
         const float sx = __builtin_bit_cast(float, (ebits & 0xffu) << 23);
         const float sy = __builtin_bit_cast(float, ((ebits >> 8) & 0xffu) << 23);
         const float sz = __builtin_bit_cast(float, ((ebits >> 16) & 0xffu) << 23);
         const uint32_t imask = ebits >> 24;
-        const uint32_t meta_w[2] = {__builtin_bit_cast(uint32_t, b4.z), __builtin_bit_cast(uint32_t, b4.w)};
+        const uint32_t present = __builtin_bit_cast(uint32_t, b4.z);
         const uint32_t qlx[2] = {__builtin_bit_cast(uint32_t, c.x), __builtin_bit_cast(uint32_t, c.y)};
         const uint32_t qly[2] = {__builtin_bit_cast(uint32_t, c.z), __builtin_bit_cast(uint32_t, c.w)};
         const uint32_t qlz[2] = {__builtin_bit_cast(uint32_t, dd.x), __builtin_bit_cast(uint32_t, dd.y)};
@@ -180,39 +223,38 @@ ERD bool trav_apply(Trav& T, const DevScene& S, bool tri_step, bool two, uint32_
         // Slab test of the eight children.  Box tests only gate the traversal, so any conservative evaluation
         // is allowed: the entry/exit planes per axis are picked by the ray's direction sign and each plane
         // distance is ONE fused multiply-add, t = q * (2^e * idir) + (p * idir - o * idir); its rounding error
-        // is covered by the absolute box padding of the builder (er_bvh.cpp).
+        // is covered by the absolute box padding of the builder (er_bvh.cpp).  The entry and exit plane of an
+        // axis share both coefficients, so they go through the packed pipe as one v_pk_fma_f32.
         const float Ax = sx * T.idir.x, Ay = sy * T.idir.y, Az = sz * T.idir.z;
         const float Bx = __builtin_fmaf(a.x, T.idir.x, T.noi.x), By = __builtin_fmaf(a.y, T.idir.y, T.noi.y), Bz = __builtin_fmaf(a.z, T.idir.z, T.noi.z);
+        const V2 A2x = {Ax, Ax}, A2y = {Ay, Ay}, A2z = {Az, Az}, B2x = {Bx, Bx}, B2y = {By, By}, B2z = {Bz, Bz};
         const bool posx = (T.oct7 & 1u) != 0, posy = (T.oct7 & 2u) != 0, posz = (T.oct7 & 4u) != 0;
         const uint32_t nx[2] = {posx ? qlx[0] : qhx[0], posx ? qlx[1] : qhx[1]}, fx[2] = {posx ? qhx[0] : qlx[0], posx ? qhx[1] : qlx[1]};
         const uint32_t ny[2] = {posy ? qly[0] : qhy[0], posy ? qly[1] : qhy[1]}, fy[2] = {posy ? qhy[0] : qly[0], posy ? qhy[1] : qly[1]};
         const uint32_t nz[2] = {posz ? qlz[0] : qhz[0], posz ? qlz[1] : qhz[1]}, fz[2] = {posz ? qhz[0] : qlz[0], posz ? qhz[1] : qlz[1]};
-        uint32_t hits = 0, tmask = 0;
+        // one accumulator: bit s = child s hit, bits 8 + 2s and 9 + 2s = its triangle slots; the node's imask and
+        // tri_present then keep the inner children and the triangles that exist -- no branch on the child kind
+        uint32_t hm = 0;
 #pragma unroll
         for (int s8 = 0; s8 < 8; s8++) {
             const int w = s8 >> 2, k = s8 & 3;
-            const uint32_t meta = (meta_w[w] >> (8 * k)) & 0xffu;
-            const float tnx = __builtin_fmaf(ubyte_f(nx[w], k), Ax, Bx), tfx = __builtin_fmaf(ubyte_f(fx[w], k), Ax, Bx);
-            const float tny = __builtin_fmaf(ubyte_f(ny[w], k), Ay, By), tfy = __builtin_fmaf(ubyte_f(fy[w], k), Ay, By);
-            const float tnz = __builtin_fmaf(ubyte_f(nz[w], k), Az, Bz), tfz = __builtin_fmaf(ubyte_f(fz[w], k), Az, Bz);
-            const float tmin = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
-            const float tmax = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+            const V2 tx = __builtin_elementwise_fma((V2){ubyte_f(nx[w], k), ubyte_f(fx[w], k)}, A2x, B2x);
+            const V2 ty = __builtin_elementwise_fma((V2){ubyte_f(ny[w], k), ubyte_f(fy[w], k)}, A2y, B2y);
+            const V2 tz = __builtin_elementwise_fma((V2){ubyte_f(nz[w], k), ubyte_f(fz[w], k)}, A2z, B2z);
+            const float tmin = __builtin_fmaxf(__builtin_fmaxf(tx.x, ty.x), tz.x);
+            const float tmax = __builtin_fminf(__builtin_fminf(tx.y, ty.y), tz.y);
             const bool hit = (tmin <= tmax) && (tmax >= 0.0f) && (tmin <= bound);
-            // meta: empty 0 and inner 1 have a zero triangle count, so they add no triangle bits; empty slots
-            // are not in imask, so they add no node bit either -- no branch on the child kind
-            const uint32_t leafbits = ((1u << (meta >> 5)) - 1u) << (meta & 31u);
-            hits |= hit ? (1u << s8) : 0u;
-            tmask |= hit ? leafbits : 0u;
+            hm |= hit ? ((1u << s8) | (3u << (8 + 2 * s8))) : 0u;
         }
         // inner hits, moved from bit `slot` to bit `slot ^ oct7` (three conditional swap stages)
-        uint32_t nmask = hits & imask;
+        uint32_t nmask = hm & imask;
         nmask = (T.oct7 & 1u) ? (((nmask & 0xAAu) >> 1) | ((nmask & 0x55u) << 1)) : nmask;
         nmask = (T.oct7 & 2u) ? (((nmask & 0xCCu) >> 2) | ((nmask & 0x33u) << 2)) : nmask;
         nmask = (T.oct7 & 4u) ? (((nmask & 0xF0u) >> 4) | ((nmask & 0x0Fu) << 4)) : nmask;
         T.ng_base = __builtin_bit_cast(uint32_t, b4.x);
         T.ng_bits = nmask | (imask << 8);
         T.tg_base = __builtin_bit_cast(uint32_t, b4.y);
-        T.tg_mask = tmask;
+        T.tg_mask = ((hm >> 8) & present) | (present << 16);
     }
     return occluded;
 }

@@ -177,14 +177,15 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
             if (exhausted) break;
             continue;
         }
-        bool finished = false, do_step = false, tri_step = false, two = false;
-        uint32_t tslot = 0, off = 0;
-        if (busy) do_step = trav_choose(T, S, stack, spill, finished, tri_step, two, tslot, off);
-        float4 a, b4, c, dd, e4, f4;
-        trav_fetch(S, do_step, tri_step, two, off, a, b4, c, dd, e4, f4);
+        bool finished = false, do_step = false;
+        TravStep st;
+        st.node = false; st.tri = false; st.two = false; st.tslot = 0; st.noff = 0; st.toff = 0;
+        if (busy) { do_step = trav_choose(T, S, stack, spill, st); finished = !do_step; }
+        TravData D;
+        trav_fetch(S, st, D);
         if (busy) {
             if (do_step) {
-                if (trav_apply<COUNT>(T, S, tri_step, two, tslot, a, b4, c, dd, e4, f4, c_nodes, c_tris)) {
+                if (trav_apply<COUNT>(T, S, st, D, c_nodes, c_tris)) {
                     W.occluded[entry] = 1;   // a certain occluder ends the shadow query
                     finished = true;
                 }
