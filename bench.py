@@ -205,7 +205,12 @@ def main():
         kernel_name = {"wavefront": "er_wf_trace", "fused": "er_fused_kernel", "megakernel": "er_render_kernel"}.get(sched, "?")
         if sched != "wavefront":
             trace_b = path_b      # the single kernel of these schedules does the whole path
-        achieved = (trace_b / t_launches) / (trace_ms_avg * 1e-3) / 1e9 if trace_ms_avg > 0 else 0.0
+        # the wavefront schedule runs `conc` slot pools side by side, each on its own stream: launches overlap, so
+        # the rate the kernel sustains is conc x (bytes of one launch / duration of one launch).  Conservative: a
+        # trace launch also shares the chip with the other pools' shade launches for part of its duration.
+        conc = max(1, int(prof.get("concurrency", 1)))
+        per_launch = (trace_b / t_launches) / (trace_ms_avg * 1e-3) / 1e9 if trace_ms_avg > 0 else 0.0
+        achieved = per_launch * conc
         traffic = None
         tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes
         if os.path.exists(tf) and world == 1 and args.tris == 1_000_000:
@@ -227,7 +232,8 @@ def main():
             "mean_path_length": round(samples / max(1, paths), 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": kernel_name, "launches": prof["trace_launches"],
+                         "kernel": kernel_name, "launches": prof["trace_launches"], "concurrent_launches": conc,
+                         "achieved_per_launch": round(per_launch, 2),
                          "avg_launch_ms": round(trace_ms_avg, 5), "algorithmic_bytes_per_launch": round(trace_b / t_launches, 1),
                          "trace_ms_total": round(prof["trace_ms"], 3), "shade_ms_total": round(prof["shade_ms"], 3),
                          "whole_path_GBps": round(path_b / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else None,

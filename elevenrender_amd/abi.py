@@ -83,7 +83,8 @@ class ErCounters(C.Structure):
 
 
 class ErProfile(C.Structure):
-    _fields_ = [("trace_ms", C.c_float), ("shade_ms", C.c_float), ("trace_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("schedule", C.c_uint32)]
+    _fields_ = [("trace_ms", C.c_float), ("shade_ms", C.c_float), ("trace_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("schedule", C.c_uint32),
+                ("concurrency", C.c_uint32)]
 
 
 class ErAccelInfo(C.Structure):

@@ -41,6 +41,7 @@ struct WfState {
     uint32_t* qs[2];   // shadow queues (slot)
     uint32_t* counts;  // WF_COUNTS words
     uint2* spill;      // per persistent trace wave: ER_BVH_MAX_DEPTH x 64 stack entries beyond the LDS levels
+    uint32_t pool, pools;   // this state drives the owned tiles t with t % pools == pool (see er_api.cpp: slot pools)
 };
 
 void er_launch_wf_begin(const DevScene& S, const WfState& W, uint32_t n_samples, hipStream_t stream);

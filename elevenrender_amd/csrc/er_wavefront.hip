@@ -18,6 +18,7 @@
 // the path's radiance (c_vis / c_occ), so shading never waits for it: the next shade step of
 // the slot resolves it first.  A path that ends while its shadow ray is in flight is re-queued
 // once with ER_WF_FINALIZE_ONLY.
+#include <cstdlib>
 #include "er_device.h"
 #include "er_kernels.h"
 #include "er_wavefront.h"
@@ -58,7 +59,7 @@ __device__ __forceinline__ void slot_pixel(const DevScene& S, uint32_t slot, uin
 
 // ---- begin: first camera ray of every slot, queue 0 = all valid slots ----
 __global__ __launch_bounds__(64) void er_wf_begin(DevScene S, WfState W, uint32_t n_samples) {
-    uint32_t slot = blockIdx.x * 64 + threadIdx.x;
+    uint32_t slot = (blockIdx.x * W.pools + W.pool) * 64 + threadIdx.x;   // this pool's share of the owned tiles
     uint32_t px, py;   // (all counters were zeroed by the memset that precedes this launch)
     slot_pixel(S, slot, px, py);
     bool valid = px < S.x_res && py < S.y_res && n_samples > 0;
@@ -88,12 +89,10 @@ __global__ __launch_bounds__(64) void er_wf_begin(DevScene S, WfState W, uint32_
 // batch of six 16-byte loads per iteration whatever mix of states its lanes are in.  A lane whose ray is done
 // writes the result and, once enough lanes are idle, the wave hands them new rays from its local chunk of the
 // queue (one global atomic per chunk) -- lanes never wait for the slowest ray of a 64-ray batch.
-#ifndef WF_REFILL_MIN
-#define WF_REFILL_MIN 16
-#endif
+#define WF_REFILL_MIN 16   // default; ER_TRACE_REFILL_MIN overrides it at run time (tuning knob; flat from 4 to 32)
 
 template <bool COUNT>
-__global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_t parity) {
+__global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_t parity, uint32_t refill_min) {
     __shared__ uint2 s_stack[WF_LDS_STACK * 64];
     const int lane = threadIdx.x;
     uint2* stack = s_stack + lane;
@@ -128,7 +127,7 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
         // ---- refill idle lanes from the wave's local chunk; one global atomic per chunk ----
         unsigned long long idle = __ballot(!busy);
         unsigned n_idle = __popcll(idle);
-        if (!exhausted && (n_idle >= WF_REFILL_MIN || n_idle == 64)) {
+        if (!exhausted && (n_idle >= refill_min || n_idle == 64)) {
             if (pool_cur >= pool_end) {
                 // XCD-aware hand-out: the queues are cut into 8 contiguous ranges, one per XCD (each XCD has its own
                 // L2).  The queues are ordered by pixel tile, so a range is a band of the image; a wave drains its
@@ -444,14 +443,20 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
 }
 
 void er_launch_wf_begin(const DevScene& S, const WfState& W, uint32_t n_samples, hipStream_t stream) {
-    if (S.owned_tile_count == 0) return;
+    if (S.owned_tile_count <= W.pool) return;
     (void)hipMemsetAsync(W.counts, 0, WF_COUNTS * sizeof(uint32_t), stream);
-    hipLaunchKernelGGL(er_wf_begin, dim3(S.owned_tile_count), dim3(64), 0, stream, S, W, n_samples);
+    const uint32_t tiles = (S.owned_tile_count - W.pool + W.pools - 1) / W.pools;
+    hipLaunchKernelGGL(er_wf_begin, dim3(tiles), dim3(64), 0, stream, S, W, n_samples);
 }
 void er_launch_wf_trace(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t blocks, hipStream_t stream) {
+    static const uint32_t refill_min = [] {
+        const char* e = getenv("ER_TRACE_REFILL_MIN");
+        int v = e ? atoi(e) : WF_REFILL_MIN;
+        return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+    }();
     if (S.owned_tile_count == 0) return;
-    if (count) hipLaunchKernelGGL(er_wf_trace<true>, dim3(blocks), dim3(64), 0, stream, S, W, parity);
-    else hipLaunchKernelGGL(er_wf_trace<false>, dim3(blocks), dim3(64), 0, stream, S, W, parity);
+    if (count) hipLaunchKernelGGL(er_wf_trace<true>, dim3(blocks), dim3(64), 0, stream, S, W, parity, refill_min);
+    else hipLaunchKernelGGL(er_wf_trace<false>, dim3(blocks), dim3(64), 0, stream, S, W, parity, refill_min);
 }
 void er_launch_wf_shade(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t blocks, hipStream_t stream) {
     if (S.owned_tile_count == 0) return;

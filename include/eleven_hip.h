@@ -202,6 +202,9 @@ typedef struct ErProfile {
     uint32_t trace_launches, shade_launches;
     uint32_t schedule;                 /* ER_FLAG_WAVEFRONT / ER_FLAG_FUSED / ER_FLAG_MEGAKERNEL actually in use; for the
                                           two single-kernel schedules trace_ms is that kernel's time and shade_ms is 0 */
+    uint32_t concurrency;              /* wavefront schedule: number of slot pools whose launches run side by side on
+                                          their own streams (their durations overlap, so trace_ms + shade_ms exceeds the
+                                          elapsed time by up to this factor); 1 otherwise */
 } ErProfile;
 int er_get_profile(ErScene* scene, ErProfile* out);
 
