@@ -421,9 +421,10 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     if (s->params.flags & ER_FLAG_FUSED) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-        s->fused_blocks = (uint32_t)prop.multiProcessorCount * 8;   // 2 waves per SIMD (register-limited)
+        s->fused_blocks = (uint32_t)prop.multiProcessorCount * 12;   // 3 waves per SIMD (register-limited, see er_fused.hip)
         if (const char* e = getenv("ER_FUSED_WAVES_PER_CU")) s->fused_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max(1, atoi(e));
-        if ((rc = upload(s->d_spill, nullptr, (size_t)s->fused_blocks * ER_BVH_MAX_DEPTH * 64, s->stream)) != ER_OK) return rc;
+        // per wave: ER_BVH_MAX_DEPTH x 64 uint2 stack entries + the same number of ints for the exact re-trace
+        if ((rc = upload(s->d_spill, nullptr, (size_t)s->fused_blocks * ER_BVH_MAX_DEPTH * 64 * 3 / 2, s->stream)) != ER_OK) return rc;
         if ((rc = upload(s->d_ticket, nullptr, 1, s->stream)) != ER_OK) return rc;
     } else if (s->params.flags & ER_FLAG_WAVEFRONT) {
         // wavefront path state: one slot per owned pixel lane.

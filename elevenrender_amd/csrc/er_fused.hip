@@ -40,19 +40,22 @@ __device__ __forceinline__ unsigned fwave_sum(unsigned v) {
 
 }  // namespace
 
+// waves per SIMD the kernel is compiled for.  Measured on C2 (full frame), waves per CU in brackets: 2 -> 863 [8];
+// 3 -> 962 [12] (66 VGPRs spilled, but half as many again resident waves); 4 -> 872 [16] (180 spilled)
 #ifndef FUSED_WAVES
-#define FUSED_WAVES 2
+#define FUSED_WAVES 3
 #endif
 template <bool COUNT>
 __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, uint32_t* ticket, uint2* spill_base, uint32_t n_samples) {
     __shared__ uint2 s_stack[WF_LDS_STACK * 64];
     __shared__ float s_park[12 * 64];      // next bounce ray (o, d) + contribution if visible / if occluded
     __shared__ float s_aov[9 * 64];        // first-bounce normal / tangent / bitangent of the current path
-    __shared__ int s_stack2[ER_STACK * 64];   // exact re-trace fallback (binary BVH)
     const int lane = threadIdx.x;
     uint2* stack = s_stack + lane;
     uint2* spill = spill_base + (size_t)blockIdx.x * (ER_STACK * 64) + lane;
-    int* stack2 = s_stack2 + lane;
+    // exact re-trace fallback (binary BVH, rare): its stack lives in HBM behind the wave's spill area, so that LDS
+    // (9.3 KB per wave) does not cap the number of resident waves
+    int* stack2 = (int*)(spill_base + (size_t)gridDim.x * (ER_STACK * 64)) + (size_t)blockIdx.x * (ER_STACK * 64) + lane;
     float* park = s_park + lane;
     float* aov = s_aov + lane;
     const uint32_t n_slots = S.owned_tile_count * 64u;

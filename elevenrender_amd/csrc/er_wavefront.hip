@@ -46,6 +46,17 @@ __device__ __forceinline__ unsigned queue_push(uint32_t* counter, bool want) {
     return base + rank;
 }
 
+// append a wave's `n` staged entries (wave-uniform n; all lanes call): one atomic, coalesced copy
+#define WF_STAGE 8
+__device__ __forceinline__ void queue_flush(uint32_t* counter, uint32_t* queue, const uint32_t* staged, unsigned n) {
+    if (n == 0) return;
+    const unsigned lane = threadIdx.x & 63;
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(counter, n);
+    base = __shfl(base, 0, 64);
+    for (unsigned i = lane; i < n; i += 64) queue[base + i] = staged[i];
+}
+
 __device__ __forceinline__ void slot_pixel(const DevScene& S, uint32_t slot, uint32_t& px, uint32_t& py) {
     uint32_t tile = S.owned_tiles[slot >> 6];
     uint32_t lane = slot & 63;
@@ -222,6 +233,10 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
 template <bool COUNT>
 __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, WfState W, uint32_t parity) {
     __shared__ int s_stack[ER_STACK * 64];   // only for the rare exact re-trace of an overflowed ray
+    // queue entries are staged per wave and appended WF_STAGE tickets at a time: the two queue-length words are
+    // single addresses, and one address takes ~90 atomics/us whatever the number of waves
+    __shared__ uint32_t s_qc[WF_STAGE * 64], s_qs[WF_STAGE * 64];
+    unsigned n_qc = 0, n_qs = 0;             // staged entries (wave-uniform)
     const int lane = threadIdx.x;
     int* stack = s_stack + lane;
     unsigned c_nodes = 0, c_tris = 0;
@@ -246,6 +261,13 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
             t_cur = base;
             t_end = base + tchunk < wC ? base + tchunk : wC;
             if (base >= wC) break;
+        }
+        if (n_qc > (WF_STAGE - 1) * 64 || n_qs > (WF_STAGE - 1) * 64) {   // no room for another ticket: append
+            __syncthreads();
+            queue_flush(&W.counts[WF_NC + WF_PAR(parity ^ 1)], qn, s_qc, n_qc);
+            queue_flush(&W.counts[WF_NS + WF_PAR(parity ^ 1)], qsn, s_qs, n_qs);
+            __syncthreads();
+            n_qc = 0; n_qs = 0;
         }
         uint32_t ticket = t_cur++;
         uint32_t item = ticket * 64 + lane;
@@ -426,11 +448,16 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
                                             __builtin_bit_cast(float, bounce | (pending ? WF_PENDING : 0u)));
             }
         }
-        unsigned pc = queue_push(&W.counts[WF_NC + WF_PAR(parity ^ 1)], push_closest);
-        if (push_closest) qn[pc] = next_entry;
-        unsigned ps = queue_push(&W.counts[WF_NS + WF_PAR(parity ^ 1)], push_shadow);
-        if (push_shadow) qsn[ps] = slot;
+        const unsigned long long mc = __ballot(push_closest), ms = __ballot(push_shadow);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (push_closest) s_qc[n_qc + __popcll(mc & below)] = next_entry;
+        if (push_shadow) s_qs[n_qs + __popcll(ms & below)] = slot;
+        n_qc += __popcll(mc);
+        n_qs += __popcll(ms);
     }
+    __syncthreads();
+    queue_flush(&W.counts[WF_NC + WF_PAR(parity ^ 1)], qn, s_qc, n_qc);
+    queue_flush(&W.counts[WF_NS + WF_PAR(parity ^ 1)], qsn, s_qs, n_qs);
     unsigned t0 = wave_sum_u(c_paths), t1 = wave_sum_u(c_bounce), t3 = wave_sum_u(c_shaded), t4 = wave_sum_u(c_hdri);
     unsigned t7 = COUNT ? wave_sum_u(c_texels) : 0;
     if (lane == 0 && t1 + t0) {
