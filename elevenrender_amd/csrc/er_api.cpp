@@ -425,7 +425,8 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
         if (const char* e = getenv("ER_FUSED_WAVES_PER_CU")) s->fused_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max(1, atoi(e));
         // per wave: ER_BVH_MAX_DEPTH x 64 uint2 stack entries + the same number of ints for the exact re-trace
         if ((rc = upload(s->d_spill, nullptr, (size_t)s->fused_blocks * ER_BVH_MAX_DEPTH * 64 * 3 / 2, s->stream)) != ER_OK) return rc;
-        if ((rc = upload(s->d_ticket, nullptr, 1, s->stream)) != ER_OK) return rc;
+        // per-wave rings of (slot, samples left) records: capacity ceil(chunks / waves) * 4 each
+        if ((rc = upload(s->d_ticket, nullptr, (owned.size() * 64 + 4 * (size_t)s->fused_blocks) * 2, s->stream)) != ER_OK) return rc;
     } else if (s->params.flags & ER_FLAG_WAVEFRONT) {
         // wavefront path state: one slot per owned pixel lane.
         // SLOT POOLS: the owned tiles are dealt round-robin to `pools` independent path pools, each with its own

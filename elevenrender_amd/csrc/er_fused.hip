@@ -3,8 +3,13 @@
 // Same arithmetic per pixel as renderingKernel (reference src/kernel.cpp:477-646) and as the other two
 // schedules of this library (er_wavefront.hip, er_kernels.hip); what changes is, again, only the schedule:
 //
-//   * persistent waves; every LANE owns one pixel at a time and runs all of that pixel's samples back to back
-//     (a pixel's samples are one RNG stream); a lane that has finished its pixel takes the next unowned pixel;
+//   * persistent waves; every WAVE owns a fixed share of the pixels (chunks of four, dealt round-robin) and keeps
+//     the ones that are not in flight in a ring of (pixel, samples left) records; a LANE takes the pixel at the
+//     head of the ring, runs ONE sample of it and puts it back at the tail.  A pixel's samples are one RNG stream,
+//     so they must run one after the other -- but not on the same lane: with whole pixels as the unit a GPU that
+//     owns 1.3 pixels per lane (an eighth of a 1080p frame) needs two rounds and idles through a third of them;
+//     with single samples as the unit all of a wave's pixels advance side by side and finish together.  The ring
+//     is private to its wave, so there is no atomic and no cross-wave ordering anywhere in this kernel;
 //   * there is NO barrier between bounces, neither across the GPU nor inside the wave: in every loop
 //     iteration the lanes that are tracing advance their ray by one traversal step (er_trav.h, one unified
 //     96-byte fetch for the whole wave), and the lanes whose ray has finished wait in a small "needs shading"
@@ -34,6 +39,9 @@ __device__ __forceinline__ unsigned fwave_sum(unsigned v) {
 #ifndef FUSED_BATCH_MIN
 #define FUSED_BATCH_MIN 32   // measured on C2: 12 -> 645, 20 -> 736, 32 -> 778, 48 -> 736 Msamples/s
 #endif
+#ifndef FUSED_BATCH_LOW
+#define FUSED_BATCH_LOW 4
+#endif
 #ifndef FUSED_REFILL_MIN
 #define FUSED_REFILL_MIN 8
 #endif
@@ -46,7 +54,7 @@ __device__ __forceinline__ unsigned fwave_sum(unsigned v) {
 #define FUSED_WAVES 3
 #endif
 template <bool COUNT>
-__global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, uint32_t* ticket, uint2* spill_base, uint32_t n_samples) {
+__global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, uint2* ring_base, uint2* spill_base, uint32_t n_samples) {
     __shared__ uint2 s_stack[WF_LDS_STACK * 64];
     __shared__ float s_park[12 * 64];      // next bounce ray (o, d) + contribution if visible / if occluded
     __shared__ float s_aov[9 * 64];        // first-bounce normal / tangent / bitangent of the current path
@@ -66,49 +74,54 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
     Trav T;
     trav_begin(T, f3s(0), f3(0, 0, 1), false, -1, 0.0f);
     int mode = M_IDLE;
-    uint32_t px = 0, py = 0, idx = 0, rs = 0, left = 0, bounce = 0;
+    uint32_t slot = 0, idx = 0, rs = 0, left = 0, bounce = 0;
     F3 light = f3s(0), reduction = f3s(1);
     bool terminal = false;   // the path is over but its last shadow ray is still being traced
     int occ_code = 0;
-    bool exhausted = n_slots == 0 || n_samples == 0;
+
+    // ---- this wave's pixels: chunks c = wave, wave + waves, ... of four consecutive slots ----
+    const uint32_t n_waves = gridDim.x, wave = blockIdx.x;
+    const uint32_t chunks = n_slots >> 2;
+    const uint32_t my_slots = (chunks > wave ? (chunks - wave + n_waves - 1) / n_waves : 0u) * 4u;
+    const uint32_t cap = ((chunks + n_waves - 1) / n_waves) * 4u;      // ring capacity = most slots any wave owns
+    uint2* ring = ring_base + (size_t)wave * cap;
+    uint32_t head = 0, tail = 0;                                       // wave-uniform, monotonic; entry i lives at i % cap
+    if (n_samples > 0) {
+        for (uint32_t i0 = 0; i0 < my_slots; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            bool valid = false;
+            uint32_t sl = 0;
+            if (i < my_slots) {
+                sl = ((wave + (i >> 2) * n_waves) << 2) | (i & 3u);
+                const uint32_t tile = S.owned_tiles[sl >> 6], l = sl & 63;
+                valid = (tile % S.tiles_x) * ER_TILE + (l & 7) < S.x_res && (tile / S.tiles_x) * ER_TILE + (l >> 3) < S.y_res;
+            }
+            const unsigned long long m = __ballot(valid);
+            if (valid) ring[tail + __popcll(m & ((1ull << lane) - 1ull))] = make_uint2(sl, n_samples);
+            tail += (uint32_t)__popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
 
     while (true) {
-        // ---- idle lanes take the next unowned pixels (one atomic for all of them) ----
-        unsigned long long idle = __ballot(mode == M_IDLE);
-        unsigned n_idle = __popcll(idle);
-        if (!exhausted && (n_idle >= FUSED_REFILL_MIN || n_idle == 64)) {
-            unsigned leader = __ffsll((long long)idle) - 1;
-            unsigned base = 0;
-            if (lane == (int)leader) base = atomicAdd(ticket, n_idle);
-            base = __shfl(base, leader, 64);
-            if (base + n_idle >= n_slots) exhausted = true;
-            if (mode == M_IDLE) {
-                unsigned slot = base + __popcll(idle & ((1ull << lane) - 1ull));
-                if (slot < n_slots) {
-                    uint32_t tile = S.owned_tiles[slot >> 6], l = slot & 63;
-                    px = (tile % S.tiles_x) * ER_TILE + (l & 7);
-                    py = (tile / S.tiles_x) * ER_TILE + (l >> 3);
-                    if (px < S.x_res && py < S.y_res) mode = M_START;
-                }
-            }
-        }
-        const unsigned long long want_batch = __ballot(mode == M_START || mode == M_SHADE || mode == M_RESOLVE || mode == M_FINALIZE);
+        // (pixels are handed out inside the batch, right after the lanes that finished a sample put theirs back)
+        const unsigned long long idle = __ballot(mode == M_IDLE);
+        // idle lanes count as waiting for the batch while the ring has pixels for them
+        const unsigned long long want_batch = __ballot(mode == M_SHADE || mode == M_RESOLVE || mode == M_FINALIZE) | (tail != head ? idle : 0ull);
         const unsigned long long tracing = __ballot(mode == M_TRACE);
-        if (want_batch == 0 && tracing == 0) {
-            if (exhausted) break;
-            continue;
-        }
+        if (want_batch == 0 && tracing == 0) break;      // nothing in flight and the ring is empty: this wave is done
 
         // ---- batch: the shading step (src/kernel.cpp:508-645) for the lanes that wait for it ----
-        if (__popcll(want_batch) >= FUSED_BATCH_MIN || tracing == 0) {
-            if (mode == M_START || mode == M_SHADE || mode == M_RESOLVE || mode == M_FINALIZE) {
-                bool fin = false, regen = false;
-                if (mode == M_START) {
-                    idx = py * S.x_res + px;
-                    rs = S.rng[idx];
-                    left = n_samples;
-                    regen = true;
-                } else if (mode == M_FINALIZE) {
+        // A full wave batches 32 lanes at a time (the shading code costs the same for 1 lane as for 64).  A wave with
+        // few pixels left -- the tail of a call, or a GPU that owns few pixels -- is bound by the latency of its
+        // longest pixel (the samples of a pixel are sequential), so there a waiting lane is served sooner.
+        const unsigned n_active = 64u - (unsigned)__popcll(idle);
+        const unsigned batch_min = n_active >= 2u * FUSED_BATCH_MIN ? FUSED_BATCH_MIN : (n_active / 2u < FUSED_BATCH_LOW ? FUSED_BATCH_LOW : n_active / 2u);
+        if (__popcll(want_batch) >= batch_min || tracing == 0) {
+            bool put_back = false;
+            if (mode == M_SHADE || mode == M_RESOLVE || mode == M_FINALIZE) {
+                bool fin = false;
+                if (mode == M_FINALIZE) {
                     fin = true;
                 } else if (mode == M_RESOLVE) {
                     // the traversal could not decide the shadow query from t-intervals: exact metric
@@ -235,22 +248,50 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
                     S.rng[idx] = rs;
                     c_paths++;
                     left--;
-                    if (left > 0) regen = true; else mode = M_IDLE;
+                    put_back = left > 0;      // the pixel's next sample goes to whichever lane reaches it first
+                    mode = M_IDLE;
                 }
-                if (regen) {
-                    // src/kernel.cpp:492-493 -- five draws, left to right
-                    float c1 = rng_next(rs), c2 = rng_next(rs), c3 = rng_next(rs), c4 = rng_next(rs), c5 = rng_next(rs);
-                    Ray ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
-                    light = f3s(0);
-                    reduction = f3s(1);
-                    bounce = 0;
-                    terminal = false;
+            }
+            // ---- ring exchange: pixels whose sample just finished go to the tail, idle lanes take the head ----
+            {
+                const uint32_t avail0 = tail - head;
+                const unsigned long long pm = __ballot(put_back);
+                if (put_back) ring[(tail + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))) % cap] = make_uint2(slot, left);
+                tail += (uint32_t)__popcll(pm);
+                const unsigned long long im = __ballot(mode == M_IDLE);
+                const uint32_t n_im = (uint32_t)__popcll(im);
+                const uint32_t take = n_im < tail - head ? n_im : tail - head;
+                // a pixel's state (rng, planes, sample count, its ring record) was stored by a lane of THIS wave:
+                // same CU, same L1 -- the stores only have to have completed.  Records of earlier batches are
+                // long complete; a wait is needed only when this batch's own records are handed out again.
+                if (take > avail0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                if (mode == M_IDLE) {
+                    const uint32_t r = (uint32_t)__popcll(im & ((1ull << lane) - 1ull));
+                    if (r < take) {
+                        const uint2 e = ring[(head + r) % cap];
+                        slot = e.x;
+                        left = e.y;
+                        const uint32_t tile = S.owned_tiles[slot >> 6], l = slot & 63;
+                        idx = ((tile / S.tiles_x) * ER_TILE + (l >> 3)) * S.x_res + (tile % S.tiles_x) * ER_TILE + (l & 7);
+                        mode = M_START;
+                    }
+                }
+                head += take;
+            }
+            // ---- start the next sample of the pixels just taken (src/kernel.cpp:492-493: five draws, left to right) ----
+            if (mode == M_START) {
+                rs = S.rng[idx];
+                float c1 = rng_next(rs), c2 = rng_next(rs), c3 = rng_next(rs), c4 = rng_next(rs), c5 = rng_next(rs);
+                Ray ray = camera_ray(S.cam, (int)(idx % S.x_res), (int)(idx / S.x_res), S.x_res, S.y_res, c1, c2, c3, c4, c5);
+                light = f3s(0);
+                reduction = f3s(1);
+                bounce = 0;
+                terminal = false;
 #pragma unroll
-                    for (int q = 0; q < 9; q++) aov[q * 64] = 0.0f;
-                    trav_begin(T, ray.o, ray.d, false, -1, __builtin_inff());
-                    c_rays++;
-                    mode = M_TRACE;
-                }
+                for (int q = 0; q < 9; q++) aov[q * 64] = 0.0f;
+                trav_begin(T, ray.o, ray.d, false, -1, __builtin_inff());
+                c_rays++;
+                mode = M_TRACE;
             }
         }
 
@@ -306,9 +347,8 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
     }
 }
 
-void er_launch_fused(const DevScene& S, uint32_t* ticket, void* spill, uint32_t n_samples, bool count, uint32_t blocks, hipStream_t stream) {
+void er_launch_fused(const DevScene& S, void* ring, void* spill, uint32_t n_samples, bool count, uint32_t blocks, hipStream_t stream) {
     if (S.owned_tile_count == 0 || n_samples == 0) return;
-    (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
-    if (count) hipLaunchKernelGGL(er_fused_kernel<true>, dim3(blocks), dim3(64), 0, stream, S, ticket, (uint2*)spill, n_samples);
-    else hipLaunchKernelGGL(er_fused_kernel<false>, dim3(blocks), dim3(64), 0, stream, S, ticket, (uint2*)spill, n_samples);
+    if (count) hipLaunchKernelGGL(er_fused_kernel<true>, dim3(blocks), dim3(64), 0, stream, S, (uint2*)ring, (uint2*)spill, n_samples);
+    else hipLaunchKernelGGL(er_fused_kernel<false>, dim3(blocks), dim3(64), 0, stream, S, (uint2*)ring, (uint2*)spill, n_samples);
 }

@@ -9,4 +9,5 @@ void er_launch_setup(const DevScene& S, hipStream_t stream);
 void er_launch_render(const DevScene& S, uint32_t n_samples, bool count, hipStream_t stream);
 void er_launch_pack(const DevScene& S, const uint32_t* tiles, uint32_t ntiles, int pass, void* dst, hipStream_t stream);
 void er_launch_unpack(const DevScene& S, const uint32_t* tiles, uint32_t ntiles, int pass, const void* src, hipStream_t stream);
-void er_launch_fused(const DevScene& S, uint32_t* ticket, void* spill, uint32_t n_samples, bool count, uint32_t blocks, hipStream_t stream);
+// ring: (owned slots + 4 per wave) uint2 records, see er_fused.hip
+void er_launch_fused(const DevScene& S, void* ring, void* spill, uint32_t n_samples, bool count, uint32_t blocks, hipStream_t stream);
