@@ -58,6 +58,9 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
     __shared__ uint2 s_stack[WF_LDS_STACK * 64];
     __shared__ float s_park[12 * 64];      // next bounce ray (o, d) + contribution if visible / if occluded
     __shared__ float s_aov[9 * 64];        // first-bounce normal / tangent / bitangent of the current path
+    __shared__ float s_job[8 * 64];        // shadow ray a lane offers to a helper: o, d, bits(slot it leaves), self-hit distance
+    __shared__ int s_mail[64];             // helper -> owner: 0 nothing yet, 1 visible, 2 occluded
+    __shared__ unsigned char s_list[64];   // k-th offering lane, for the k-th free lane
     const int lane = threadIdx.x;
     uint2* stack = s_stack + lane;
     uint2* spill = spill_base + (size_t)blockIdx.x * (ER_STACK * 64) + lane;
@@ -66,6 +69,8 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
     int* stack2 = (int*)(spill_base + (size_t)gridDim.x * (ER_STACK * 64)) + (size_t)blockIdx.x * (ER_STACK * 64) + lane;
     float* park = s_park + lane;
     float* aov = s_aov + lane;
+    volatile int* mail = s_mail;
+    s_mail[lane] = 0;
     const uint32_t n_slots = S.owned_tile_count * 64u;
     const size_t npx = (size_t)S.x_res * S.y_res;
     const int hw = S.hdri_tex.width, hh = S.hdri_tex.height;
@@ -78,6 +83,14 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
     F3 light = f3s(0), reduction = f3s(1);
     bool terminal = false;   // the path is over but its last shadow ray is still being traced
     int occ_code = 0;
+    // Shadow helpers.  A pixel's samples -- and the bounces of a sample -- are a sequential chain, and when a wave has
+    // fewer pixels than lanes (a GPU that owns few pixels; the tail of a call) that chain is all that matters.  Half
+    // of it is shadow rays, whose only effect is to select one of two parked contributions: a lane with nothing to
+    // do traces the shadow ray of another lane, which meanwhile goes on with its next bounce, and reports through
+    // s_mail.  The owner adds the selected contribution before it touches `light` again, so the order of the
+    // additions -- and with it every bit of the result -- is unchanged.
+    int owner = -1;          // >= 0: this lane is tracing a shadow ray for lane `owner`
+    bool sh_out = false;     // this lane's last shadow query is with a helper
 
     // ---- this wave's pixels: chunks c = wave, wave + waves, ... of four consecutive slots ----
     const uint32_t n_waves = gridDim.x, wave = blockIdx.x;
@@ -107,9 +120,12 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
         // (pixels are handed out inside the batch, right after the lanes that finished a sample put theirs back)
         const unsigned long long idle = __ballot(mode == M_IDLE);
         // idle lanes count as waiting for the batch while the ring has pixels for them
-        const unsigned long long want_batch = __ballot(mode == M_SHADE || mode == M_RESOLVE || mode == M_FINALIZE) | (tail != head ? idle : 0ull);
+        // (a lane whose shadow query is still with a helper cannot shade yet)
+        const bool mail_ok = !sh_out || mail[lane] != 0;
+        const unsigned long long want_batch = __ballot((mode == M_SHADE || mode == M_RESOLVE || mode == M_FINALIZE) && mail_ok) | (tail != head ? idle : 0ull);
         const unsigned long long tracing = __ballot(mode == M_TRACE);
         if (want_batch == 0 && tracing == 0) break;      // nothing in flight and the ring is empty: this wave is done
+        // (a lane that waits for mail has a helper that is tracing or waiting for the batch, so this cannot strand it)
 
         // ---- batch: the shading step (src/kernel.cpp:508-645) for the lanes that wait for it ----
         // A full wave batches 32 lanes at a time (the shading code costs the same for 1 lane as for 64).  A wave with
@@ -118,9 +134,15 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
         const unsigned n_active = 64u - (unsigned)__popcll(idle);
         const unsigned batch_min = n_active >= 2u * FUSED_BATCH_MIN ? FUSED_BATCH_MIN : (n_active / 2u < FUSED_BATCH_LOW ? FUSED_BATCH_LOW : n_active / 2u);
         if (__popcll(want_batch) >= batch_min || tracing == 0) {
-            bool put_back = false;
-            if (mode == M_SHADE || mode == M_RESOLVE || mode == M_FINALIZE) {
+            bool put_back = false, offer = false;
+            if ((mode == M_SHADE || mode == M_RESOLVE || mode == M_FINALIZE) && mail_ok) {
                 bool fin = false;
+                if (sh_out) {            // the helper has answered: the contribution of the previous bounce, in order
+                    const int r = mail[lane];
+                    light = light + (r == 2 ? f3(park[9 * 64], park[10 * 64], park[11 * 64]) : f3(park[6 * 64], park[7 * 64], park[8 * 64]));
+                    mail[lane] = 0;
+                    sh_out = false;
+                }
                 if (mode == M_FINALIZE) {
                     fin = true;
                 } else if (mode == M_RESOLVE) {
@@ -128,6 +150,11 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
                     Ray sr;
                     sr.o = T.o; sr.d = T.d;
                     bool occ = resolve_shadow<COUNT>(S, stack2, sr, T.skip, T.limit, occ_code, T.s0, T.s1, c_nodes, c_tris);
+                    if (owner >= 0) {
+                        mail[owner] = occ ? 2 : 1;
+                        owner = -1;
+                        mode = M_IDLE;
+                    } else {
                     light = light + (occ ? f3(park[9 * 64], park[10 * 64], park[11 * 64]) : f3(park[6 * 64], park[7 * 64], park[8 * 64]));
                     if (terminal) {
                         fin = true;
@@ -135,6 +162,7 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
                         trav_begin(T, f3(park[0], park[64], park[128]), f3(park[192], park[256], park[320]), false, -1, __builtin_inff());
                         c_rays++;
                         mode = M_TRACE;
+                    }
                     }
                 } else {   // M_SHADE: one iteration of the bounce loop
                     Ray ray;
@@ -218,6 +246,13 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
                             c_rays++;
                             terminal = done;
                             mode = M_TRACE;
+                            if (!done) {   // offer the shadow ray to a free lane (below); taken -> this lane traces the parked ray now
+                                float* job = s_job + lane;
+                                job[0] = sr.o.x; job[64] = sr.o.y; job[128] = sr.o.z;
+                                job[192] = sr.d.x; job[256] = sr.d.y; job[320] = sr.d.z;
+                                job[384] = __builtin_bit_cast(float, hslot); job[448] = d_self;
+                                offer = true;
+                            }
                         } else if (!done) {
                             trav_begin(T, ray.o, ray.d, false, -1, __builtin_inff());
                             c_rays++;
@@ -278,6 +313,29 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
                 }
                 head += take;
             }
+            // ---- shadow helpers: lanes that are still free take the shadow rays offered in this batch ----
+            {
+                const unsigned long long om = __ballot(offer), fm = __ballot(mode == M_IDLE);
+                const unsigned n_o = (unsigned)__popcll(om), n_f = (unsigned)__popcll(fm);
+                const unsigned n_match = n_o < n_f ? n_o : n_f;
+                if (n_match > 0) {
+                    const unsigned below_o = (unsigned)__popcll(om & ((1ull << lane) - 1ull)), below_f = (unsigned)__popcll(fm & ((1ull << lane) - 1ull));
+                    if (offer && below_o < n_match) s_list[below_o] = (unsigned char)lane;
+                    __syncthreads();
+                    if (mode == M_IDLE && below_f < n_match) {
+                        const int o = s_list[below_f];
+                        const float* job = s_job + o;
+                        trav_begin(T, f3(job[0], job[64], job[128]), f3(job[192], job[256], job[320]), true, __builtin_bit_cast(int, job[384]), job[448]);
+                        owner = o;
+                        mode = M_TRACE;
+                    }
+                    if (offer && below_o < n_match) {
+                        trav_begin(T, f3(park[0], park[64], park[128]), f3(park[192], park[256], park[320]), false, -1, __builtin_inff());
+                        c_rays++;
+                        sh_out = true;
+                    }
+                }
+            }
             // ---- start the next sample of the pixels just taken (src/kernel.cpp:492-493: five draws, left to right) ----
             if (mode == M_START) {
                 rs = S.rng[idx];
@@ -313,6 +371,10 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
                 if (finished) {
                     if (!T.shadow) {
                         mode = M_SHADE;
+                    } else if (code <= 1 && owner >= 0) {
+                        mail[owner] = code ? 2 : 1;
+                        owner = -1;
+                        mode = M_IDLE;
                     } else if (code <= 1) {
                         // the shadow query's outcome only selects which precomputed contribution is added
                         light = light + (code ? f3(park[9 * 64], park[10 * 64], park[11 * 64]) : f3(park[6 * 64], park[7 * 64], park[8 * 64]));
