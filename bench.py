@@ -28,18 +28,25 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICR
 
 
 def trace_bytes(c):
-    """Algorithmic bytes of the dominant kernel er_wf_trace (DESIGN.md "Roofline accounting"): per node step one
-    80-byte ErNode8, per triangle test one 48-byte record, per ray 32 bytes of ray in and 8 bytes of result out."""
+    """Algorithmic bytes of the traversal, SURVEY.md 8(d): 64 B per node visit + 36 B per triangle test (its
+    per-pixel-sample formula restricted to the terms the trace kernel executes).  V and T are this build's own
+    event counts (8-wide nodes, two-triangle leaves)."""
+    return 64 * c["node_visits"] + 36 * c["tri_tests"]
+
+
+def trace_bytes_layout(c):
+    """The same events priced at this build's record sizes (80-byte ErNode8, 48-byte triangle record, 40 bytes
+    of ray in / result out per ray) -- what the kernel actually asks the memory system for."""
     return 80 * c["node_visits"] + 48 * c["tri_tests"] + 40 * c["rays"]
 
 
 def path_bytes(c, hdri_texels):
-    """Algorithmic bytes of the whole per-sample path: traversal + per shaded hit the 48-byte record and the
-    112-byte attribute record + texels + the HDRI CDF search (the reference's ceil(log2 P) 4-byte probes) +
-    per finished path 144 bytes of framebuffer/RNG/sample-count read-modify-write."""
+    """SURVEY.md 8(d), whole per-sample path: 64 V + 36 T + 112 H + 12 X + 4 ceil(log2 P) S + 112 per pixel-sample
+    (H shaded hits, X texel fetches, S HDRI CDF samples of a P-texel HDRI; the trailing 112 B is the framebuffer,
+    RNG and sample-count read-modify-write of one finished path)."""
     cdf_steps = max(1, math.ceil(math.log2(max(2, hdri_texels))))
-    return (trace_bytes(c) + 160 * c["shaded_hits"] + 12 * c["texel_fetches"] + 4 * cdf_steps * c["hdri_samples"]
-            + 144 * c["paths"])
+    return (trace_bytes(c) + 112 * c["shaded_hits"] + 12 * c["texel_fetches"] + 4 * cdf_steps * c["hdri_samples"]
+            + 112 * c["paths"])
 
 
 def cpu_baseline(scene, max_bounces, budget_s=18.0):
@@ -198,6 +205,7 @@ def main():
         my_rays = c_after["rays"] - c_before["rays"]
         # per-ray statistics of the instrumented replay scale the timed region's ray count
         trace_b = trace_bytes(ci) / max(1, ci["rays"]) * my_rays
+        layout_b = trace_bytes_layout(ci) / max(1, ci["rays"]) * my_rays
         path_b = path_bytes(ci, hdri_texels) / max(1, ci["bounce_samples"]) * my_samples
         t_launches = max(1, prof["trace_launches"])
         trace_ms_avg = prof["trace_ms"] / t_launches
@@ -205,6 +213,7 @@ def main():
         kernel_name = {"wavefront": "er_wf_trace", "fused": "er_fused_kernel", "megakernel": "er_render_kernel"}.get(sched, "?")
         if sched != "wavefront":
             trace_b = path_b      # the single kernel of these schedules does the whole path
+            layout_b = path_b + (layout_b - trace_bytes(ci) / max(1, ci["rays"]) * my_rays)
         # the wavefront schedule runs `conc` slot pools side by side, each on its own stream: launches overlap, so
         # the rate the kernel sustains is conc x (bytes of one launch / duration of one launch).  Conservative: a
         # trace launch also shares the chip with the other pools' shade launches for part of its duration.
@@ -234,6 +243,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": kernel_name, "launches": prof["trace_launches"], "concurrent_launches": conc,
                          "achieved_per_launch": round(per_launch, 2),
+                         "achieved_own_layout": round(per_launch * conc * layout_b / max(trace_b, 1.0), 2),
                          "avg_launch_ms": round(trace_ms_avg, 5), "algorithmic_bytes_per_launch": round(trace_b / t_launches, 1),
                          "trace_ms_total": round(prof["trace_ms"], 3), "shade_ms_total": round(prof["shade_ms"], 3),
                          "whole_path_GBps": round(path_b / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else None,
