@@ -161,25 +161,29 @@ def blob_instances(n_instances=10000, tris_per_blob=1000, x_res=3840, y_res=2160
     """C4: instances of a ~1000-triangle smooth blob (subdivided octahedron with radial noise, SMOOTH vertex
     normals) flattened into world-space triangles on a jittered grid (the reference has no instancing:
     MeshObject is a triangle range, src/MeshObject.hpp:14-22)."""
-    # unit blob: octahedron subdivided until >= tris_per_blob faces
-    verts = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float64)
-    faces = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]], np.int64)
-    while len(faces) * 4 <= max(tris_per_blob, 8) * 1.1:
-        mid = {}
-        vl = [tuple(p) for p in verts]
-        nf = []
-        def midpoint(a, b):
-            k = (min(a, b), max(a, b))
-            if k not in mid:
-                p = (np.array(vl[a]) + np.array(vl[b])) / 2
-                p = p / np.linalg.norm(p)
-                vl.append(tuple(p))
-                mid[k] = len(vl) - 1
-            return mid[k]
-        for a, b, c in faces:
-            ab, bc, ca = midpoint(a, b), midpoint(b, c), midpoint(c, a)
-            nf += [[a, ab, ca], [ab, b, bc], [ca, bc, c], [ab, bc, ca]]
-        verts, faces = np.array(vl, np.float64), np.array(nf, np.int64)
+    # unit blob: octahedron with every face cut into f x f triangles (8 f^2 faces, f chosen nearest to tris_per_blob:
+    # 968 for 1000), vertices pushed onto the unit sphere and shared between faces so the normals come out smooth
+    f = max(1, int(round(np.sqrt(max(tris_per_blob, 8) / 8.0))))
+    octa = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float64)
+    octa_faces = [[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]]
+    pts, tri = [], []
+    for a, b, c in octa_faces:
+        base = len(pts)
+        index = {}
+        for i in range(f + 1):
+            for j in range(f + 1 - i):
+                p = (octa[a] * (f - i - j) + octa[b] * i + octa[c] * j) / f
+                index[(i, j)] = base + len(index)
+                pts.append(p / np.linalg.norm(p))
+        for i in range(f):
+            for j in range(f - i):
+                tri.append([index[(i, j)], index[(i + 1, j)], index[(i, j + 1)]])
+                if i + j < f - 1:
+                    tri.append([index[(i + 1, j)], index[(i + 1, j + 1)], index[(i, j + 1)]])
+    pts = np.array(pts, np.float64)
+    _, first, inverse = np.unique(np.round(pts, 9), axis=0, return_index=True, return_inverse=True)
+    verts = pts[first]
+    faces = inverse.reshape(-1)[np.array(tri, np.int64)]
     bump = 1.0 + 0.15 * np.sin(5 * verts[:, 0]) * np.sin(4 * verts[:, 1] + 1.0) * np.sin(3 * verts[:, 2] + 2.0)
     verts = verts * bump[:, None]
     # smooth vertex normals: area-weighted face normals

@@ -235,3 +235,79 @@ def test_fused_schedule_equals_wavefront_schedule(scene_kind):
     assert (a["rng"] == b["rng"]).all() and (a["samples"] == b["samples"]).all()
     assert a["counters"]["bounce_samples"] == b["counters"]["bounce_samples"]
     assert a["counters"]["paths"] == b["counters"]["paths"]
+
+
+def _empty_scene(x_res, y_res):
+    sc = scenes.soup(1, x_res, y_res, seed=3, hdri_size=(64, 32))
+    keep = np.zeros(0, np.int64)
+    for name in ("vertices", "normals", "tangents", "uvs", "tangent_sign", "material_id"):
+        setattr(sc, name, np.ascontiguousarray(getattr(sc, name)[keep]))
+    sc.tri_count = 0
+    sc._desc = None
+    return sc
+
+
+@pytest.mark.parametrize("flags", [abi.FLAG_WAVEFRONT, abi.FLAG_FUSED, abi.FLAG_MEGAKERNEL])
+def test_edge_cases_bit_exact(oracle_mod, flags):
+    """Inputs at the edges of the domain, in every schedule: no triangles at all (every ray sees the HDRI), a frame
+    smaller than one tile and frames with partial tiles on both edges, zero-area and duplicated triangles (exactly
+    equal hit distances are the one documented source of non-bit-exact pixels, so duplicates are offset by 1e-3)."""
+    sc = _empty_scene(17, 9)
+    compare(gpu_render(sc, 3, max_bounces=8, flags=flags), oracle_render(oracle_mod, sc, 3, max_bounces=8), what="empty scene")
+    sc = scenes.soup(1, 5, 3, seed=11, hdri_size=(64, 32))
+    compare(gpu_render(sc, 4, max_bounces=8, flags=flags), oracle_render(oracle_mod, sc, 4, max_bounces=8), what="one triangle, 5x3")
+    sc = scenes.soup(600, 29, 23, seed=21, hdri_size=(64, 32))
+    v = sc.vertices.reshape(-1, 3, 3)
+    v[::7, 2] = v[::7, 1]                   # zero-area: two equal corners
+    v[1::11] = v[0::11][: len(v[1::11])] + np.float32(1e-3)   # near-duplicates of other triangles
+    sc.vertices = np.ascontiguousarray(v.reshape(sc.vertices.shape))
+    sc._desc = None
+    compare(gpu_render(sc, 3, max_bounces=8, flags=flags), oracle_render(oracle_mod, sc, 3, max_bounces=8), what="degenerate soup")
+
+
+def _window_schedules_agree(sc, spp, max_bounces, rank, world, mega_ties=0.0):
+    """wavefront == fused bit for bit (same traversal order); the megakernel walks the binary BVH, so on closed
+    meshes it may resolve an exact distance tie on a shared edge the other way (`mega_ties` = tolerated pixel fraction;
+    the two pixels found on C4 were checked against the oracle in both of its traversal orders: wavefront's answer)."""
+    w = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_WAVEFRONT)
+    f = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_FUSED)
+    m = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_MEGAKERNEL)
+    owned = w["samples"].reshape(w["beauty"].shape[:2]) > 1
+    for p in ("beauty", "normal", "tangent", "bitangent"):
+        assert (w[p].view(np.uint32) == f[p].view(np.uint32)).all(), p
+        differ = (w[p].view(np.uint32) != m[p].view(np.uint32)).any(-1)
+        assert differ.sum() <= mega_ties * owned.sum(), (p, int(differ.sum()))
+    assert (w["rng"] == f["rng"]).all() and (w["rng"] != m["rng"]).sum() <= mega_ties * owned.sum()
+    assert w["counters"]["bounce_samples"] == f["counters"]["bounce_samples"]
+    if mega_ties == 0.0:
+        assert w["counters"]["bounce_samples"] == m["counters"]["bounce_samples"]
+    return w
+
+
+def test_c5_full_size_properties():
+    """BASELINE config 5 at full size: 1M triangles, 64 materials with 192 value-noise textures of 256x256, clearcoat /
+    anisotropic / sheen variants, 16 bounces, 1920x1080 (point lights: the reference defines no result).
+    The three schedules agree bit for bit on a window of tiles; chunked calls equal one call on that window."""
+    sc = scenes.torture(1_000_000, 1920, 1080, seed=12345)
+    w = _window_schedules_agree(sc, 2, 16, rank=5, world=48)
+    c = gpu_render(sc, 2, max_bounces=16, rank=5, world=48, chunks=[1, 1])
+    assert (w["beauty"].view(np.uint32) == c["beauty"].view(np.uint32)).all()
+    assert np.isfinite(w["beauty"]).all() and w["beauty"][..., :3].max() <= 10
+    assert w["counters"]["texel_fetches"] == 0 and w["counters"]["shaded_hits"] > 0      # texel counter needs ER_FLAG_COUNTERS
+
+
+def test_c4_full_size_properties():
+    """BASELINE config 4 at full size: 9.68M triangles (10 000 instances of a 968-triangle smooth-normal blob), 3840x2160.
+    Whole frame once (finite, clamped, every path counted, sample plane = calls + 1), then the three schedules bit for
+    bit on a window of tiles, which must also equal the whole-frame render on the pixels it owns."""
+    sc = scenes.blob_instances()
+    assert sc.tri_count == 9_680_000 and (sc.x_res, sc.y_res) == (3840, 2160)
+    a = gpu_render(sc, 2, max_bounces=8)
+    assert a["counters"]["paths"] == 3840 * 2160 * 2
+    assert (a["samples"] == 3).mean() > 0.999
+    assert np.isfinite(a["beauty"]).all() and a["beauty"][..., :3].min() >= 0 and a["beauty"][..., :3].max() <= 10
+    w = _window_schedules_agree(sc, 2, 8, rank=11, world=96, mega_ties=1e-4)
+    from elevenrender_amd import dist as erdist
+    idx = erdist.tile_pixel_index(erdist.owned_tiles(11, 96, 3840, 2160), 3840, 2160)
+    idx = idx[idx >= 0]
+    assert (w["beauty"].reshape(-1, 4)[idx].view(np.uint32) == a["beauty"].reshape(-1, 4)[idx].view(np.uint32)).all()
