@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=18.0)
     ap.add_argument("--per-step-launch", action="store_true", help="one launch per step instead of one launch for all K steps")
     ap.add_argument("--schedule", choices=["auto", "wavefront", "fused", "megakernel"], default="auto")
+    ap.add_argument("--gpu-build", action="store_true", help="build the BVH on the GPU (ER_FLAG_GPU_BUILD) instead of the host SAH build")
     ap.add_argument("--sim-world", type=int, default=0, help="(diagnostic) render only rank --sim-rank's tiles of this many, no collective")
     ap.add_argument("--sim-rank", type=int, default=0)
     args = ap.parse_args()
@@ -129,7 +130,8 @@ def main():
     shard_rank, shard_world = (args.sim_rank, args.sim_world) if (args.sim_world > 1 and world == 1) else (rank, world)
     sched_flag = {"auto": 0, "wavefront": abi.FLAG_WAVEFRONT, "fused": abi.FLAG_FUSED, "megakernel": abi.FLAG_MEGAKERNEL}[args.schedule]
     pars = render.RenderParameters(sampleTarget=256, max_bounces=args.max_bounces, device=f"hip:{local_rank}",
-                                   rank=shard_rank, world=shard_world, flags=abi.FLAG_PROFILE | sched_flag)
+                                   rank=shard_rank, world=shard_world,
+                                   flags=abi.FLAG_PROFILE | sched_flag | (abi.FLAG_GPU_BUILD if args.gpu_build else 0))
     rm = render.RenderingManager(pars)
     rm.start_rendering(scene)
     accel = rm.accel_info()
@@ -194,7 +196,7 @@ def main():
         # ---- roofline: algorithmic bytes per launch from an instrumented replay of the same samples ----
         inst = render.RenderingManager(render.RenderParameters(sampleTarget=256, max_bounces=args.max_bounces,
                                                                device=f"hip:{local_rank}", rank=shard_rank, world=shard_world,
-                                                               flags=abi.FLAG_COUNTERS | sched_flag))
+                                                               flags=abi.FLAG_COUNTERS | sched_flag | (abi.FLAG_GPU_BUILD if args.gpu_build else 0)))
         inst.start_rendering(scene)
         n_inst = min(2, args.steps)
         inst.render(n_inst)
@@ -250,7 +252,7 @@ def main():
                          "node_visits_per_ray": round(ci["node_visits"] / max(1, ci["rays"]), 2),
                          "tri_tests_per_ray": round(ci["tri_tests"] / max(1, ci["rays"]), 2)},
             "accel": {"nodes": accel["node_count"], "node_bytes": accel["node_bytes"], "leaves": accel["leaf_count"],
-                      "max_depth": accel["max_depth"], "build_ms": round(accel["build_ms"], 1), "upload_ms": round(accel["upload_ms"], 2)},
+                      "max_depth": accel["max_depth"], "build_ms": round(accel["build_ms"], 1), "builder": "device linear BVH" if accel["builder"] else "host binned SAH", "upload_ms": round(accel["upload_ms"], 2)},
             "readback_ms": round(readback_ms, 2), "beauty_mean": beauty_mean,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -17,7 +17,7 @@ ER_OK = 0
 ER_ERR_INVALID_ARG, ER_ERR_NO_DEVICE, ER_ERR_HIP, ER_ERR_STATE, ER_ERR_OOM = -1, -2, -3, -4, -5
 PASS_BEAUTY, PASS_DENOISE, PASS_NORMAL, PASS_TANGENT, PASS_BITANGENT, PASS_COUNT = 0, 1, 2, 3, 4, 5
 PASS_NAMES = {"beauty": 0, "denoise": 1, "normal": 2, "tangent": 3, "bitangent": 4}
-FLAG_POINT_LIGHTS, FLAG_COUNTERS, FLAG_MEGAKERNEL, FLAG_PROFILE, FLAG_FUSED, FLAG_WAVEFRONT = 1, 2, 4, 8, 16, 32
+FLAG_POINT_LIGHTS, FLAG_COUNTERS, FLAG_MEGAKERNEL, FLAG_PROFILE, FLAG_FUSED, FLAG_WAVEFRONT, FLAG_GPU_BUILD = 1, 2, 4, 8, 16, 32, 64
 
 
 class ErVec3(C.Structure):
@@ -90,7 +90,7 @@ class ErProfile(C.Structure):
 class ErAccelInfo(C.Structure):
     _fields_ = [("node_count", C.c_uint32), ("node_bytes", C.c_uint32), ("leaf_count", C.c_uint32),
                 ("max_depth", C.c_uint32), ("tri_record_bytes", C.c_uint32), ("build_ms", C.c_float),
-                ("upload_ms", C.c_float), ("lift_bound", C.c_float)]
+                ("upload_ms", C.c_float), ("lift_bound", C.c_float), ("builder", C.c_uint32)]
 
 
 # every symbol include/eleven_hip.h declares: name -> (restype, argtypes)

@@ -15,7 +15,9 @@
 #include <vector>
 
 #include "../../include/eleven_hip.h"
+#include <chrono>
 #include "er_bvh.h"
+#include "er_gpu_build.h"
 #include "er_device.h"
 #include "er_kernels.h"
 #include "er_wavefront.h"
@@ -343,45 +345,78 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     HIP_TRY(hipEventCreate(&s->ev_start));
     HIP_TRY(hipEventCreate(&s->ev_stop));
 
-    // ---- acceleration structure (host) ----
-    ErBvhBuild bvh;
-    er_build_bvh(s->vertices.data(), s->normals.data(), s->tri_count, 0, &bvh);
-    if (bvh.max_depth > ER_BVH_MAX_DEPTH) return fail(ER_ERR_STATE, "er_render_begin: BVH deeper than the traversal stack");
-    size_t n = s->tri_count;
-    std::vector<ErTriIsect> isect(n + 1);      // +1: the wide traversal fetches triangles in pairs
-    std::vector<ErTriAttr> attr(n);
-    for (size_t slot = 0; slot < n; slot++) {
-        uint32_t id = bvh.slot_to_tri[slot];
-        const float* v = &s->vertices[(size_t)id * 9];
-        ErTriIsect& r = isect[slot];
-        memcpy(r.v0, v, 12); memcpy(r.v1, v + 3, 12); memcpy(r.v2, v + 6, 12);
-        r.tri_id = (int32_t)id;
-        r.lift = bvh.tri_lift[id];
-        r.sign = s->tangent_sign[id];
-        ErTriAttr& a = attr[slot];
-        memcpy(a.n, &s->normals[(size_t)id * 9], 36);
-        memcpy(a.t, &s->tangents[(size_t)id * 9], 36);
-        memcpy(a.uv, &s->uvs[(size_t)id * 6], 24);
-        a.material = s->material_id[id];
-        a.pad[0] = a.pad[1] = a.pad[2] = 0;
-    }
+    // ---- acceleration structure: host binned-SAH build (default) or device linear-BVH build ----
+    // What the rest of this function needs from either builder:
+    size_t n = s->tri_count, n8_pieces = 0;
+    uint32_t bvh2_nodes = 0, wide_nodes = 0, wide_depth = 0, leaf_count = 0;
+    float bvh_lo[3] = {0, 0, 0}, bvh_hi[3] = {0, 0, 0}, lift_bound = 0;
+    double build_ms = 0;
+    bool built = false;
+    int rc;
     hipEvent_t u0, u1;
     HIP_TRY(hipEventCreate(&u0));
     HIP_TRY(hipEventCreate(&u1));
-    HIP_TRY(hipEventRecord(u0, s->stream));
-    int rc;
-    if ((rc = upload(s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * 4, s->stream)) != ER_OK) return rc;
-    memset(&isect[n], 0, sizeof(ErTriIsect));
-    // wide nodes and triangle records share ONE buffer: the wide traversal addresses both with a 32-bit
-    // offset in 16-byte units (its lanes exchange fetch addresses with one ds_bpermute per load)
-    const size_t n8_pieces = bvh.nodes8.size() * 5 + 3;   // + padding: a step fetches 96 B from a node's start
-    std::vector<float4> geom(n8_pieces + (n + 1) * 3, make_float4(0, 0, 0, 0));
-    if (!bvh.nodes8.empty()) memcpy(geom.data(), bvh.nodes8.data(), bvh.nodes8.size() * sizeof(ErNode8));
-    memcpy(geom.data() + n8_pieces, isect.data(), (n + 1) * sizeof(ErTriIsect));
-    if (geom.size() >= (1ull << 30)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: geometry exceeds the 16 GB addressable by the wide traversal");
-    if ((rc = upload(s->d_nodes8, geom.data(), geom.size(), s->stream)) != ER_OK) return rc;
-    if (bvh.max_depth8 > ER_BVH_MAX_DEPTH) return fail(ER_ERR_STATE, "er_render_begin: wide BVH deeper than the traversal stack");
-    if ((rc = upload(s->d_attr, attr.data(), n * 7, s->stream)) != ER_OK) return rc;
+    if (((p->flags & ER_FLAG_GPU_BUILD) || getenv("ER_GPU_BUILD")) && s->tri_count > ER_BVH_LEAF_MAX) {
+        // whole structure on the device (er_gpu_build.hip): tree, wide-node collapse, slot order, triangle records
+        std::string why;
+        ErGpuSceneArrays arrays{s->vertices.data(), s->normals.data(), s->tangents.data(), s->uvs.data(), s->tangent_sign.data(), s->material_id.data()};
+        ErGpuBvhDevice g;
+        int brc = er_gpu_build_device(arrays, s->tri_count, s->device, &g, why);
+        if (brc < 0) return fail(ER_ERR_HIP, "er_render_begin: device BVH build: " + why);
+        if (brc == 0) {
+            if (g.geom_f4 >= (1ull << 30)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: geometry exceeds the 16 GB addressable by the wide traversal");
+            s->d_nodes.release(); s->d_nodes8.release(); s->d_attr.release();
+            s->d_nodes.p = g.nodes; s->d_nodes.n = g.nodes_f4;
+            s->d_nodes8.p = g.geom; s->d_nodes8.n = g.geom_f4;
+            s->d_attr.p = g.attr; s->d_attr.n = g.attr_f4;
+            n8_pieces = g.n8_pieces;
+            bvh2_nodes = (uint32_t)(g.nodes_f4 / 4); wide_nodes = g.nodes8_count; wide_depth = g.max_depth8; leaf_count = g.leaf_count;
+            for (int a = 0; a < 3; a++) { bvh_lo[a] = g.lo[a]; bvh_hi[a] = g.hi[a]; }
+            lift_bound = g.lift_bound;
+            build_ms = g.build_ms;
+            built = true;
+        }   // brc > 0: the device builder declined (tree too deep for the traversal stacks): host build
+    }
+    if (built) HIP_TRY(hipEventRecord(u0, s->stream));
+    if (!built) {
+        ErBvhBuild bvh;
+        er_build_bvh(s->vertices.data(), s->normals.data(), s->tri_count, 0, &bvh);
+        HIP_TRY(hipEventRecord(u0, s->stream));
+        if (bvh.max_depth > ER_BVH_MAX_DEPTH) return fail(ER_ERR_STATE, "er_render_begin: BVH deeper than the traversal stack");
+        if (bvh.max_depth8 > ER_BVH_MAX_DEPTH) return fail(ER_ERR_STATE, "er_render_begin: wide BVH deeper than the traversal stack");
+        std::vector<ErTriIsect> isect(n + 1);      // +1: the wide traversal fetches triangles in pairs
+        std::vector<ErTriAttr> attr(n);
+        for (size_t slot = 0; slot < n; slot++) {
+            uint32_t id = bvh.slot_to_tri[slot];
+            const float* v = &s->vertices[(size_t)id * 9];
+            ErTriIsect& r = isect[slot];
+            memcpy(r.v0, v, 12); memcpy(r.v1, v + 3, 12); memcpy(r.v2, v + 6, 12);
+            r.tri_id = (int32_t)id;
+            r.lift = bvh.tri_lift[id];
+            r.sign = s->tangent_sign[id];
+            ErTriAttr& a = attr[slot];
+            memcpy(a.n, &s->normals[(size_t)id * 9], 36);
+            memcpy(a.t, &s->tangents[(size_t)id * 9], 36);
+            memcpy(a.uv, &s->uvs[(size_t)id * 6], 24);
+            a.material = s->material_id[id];
+            a.pad[0] = a.pad[1] = a.pad[2] = 0;
+        }
+        if ((rc = upload(s->d_nodes, bvh.nodes.data(), bvh.nodes.size() * 4, s->stream)) != ER_OK) return rc;
+        memset(&isect[n], 0, sizeof(ErTriIsect));
+        // wide nodes and triangle records share ONE buffer: the wide traversal addresses both with a 32-bit
+        // offset in 16-byte units
+        n8_pieces = bvh.nodes8.size() * 5 + 3;   // + padding: a step fetches 96 B from a node's start
+        std::vector<float4> geom(n8_pieces + (n + 1) * 3, make_float4(0, 0, 0, 0));
+        if (!bvh.nodes8.empty()) memcpy(geom.data(), bvh.nodes8.data(), bvh.nodes8.size() * sizeof(ErNode8));
+        memcpy(geom.data() + n8_pieces, isect.data(), (n + 1) * sizeof(ErTriIsect));
+        if (geom.size() >= (1ull << 30)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: geometry exceeds the 16 GB addressable by the wide traversal");
+        if ((rc = upload(s->d_nodes8, geom.data(), geom.size(), s->stream)) != ER_OK) return rc;
+        if ((rc = upload(s->d_attr, attr.data(), n * 7, s->stream)) != ER_OK) return rc;
+        bvh2_nodes = (uint32_t)bvh.nodes.size(); wide_nodes = (uint32_t)bvh.nodes8.size(); wide_depth = bvh.max_depth8; leaf_count = bvh.leaf_count;
+        for (int a = 0; a < 3; a++) { bvh_lo[a] = bvh.lo[a]; bvh_hi[a] = bvh.hi[a]; }
+        lift_bound = bvh.lift_bound;
+        build_ms = bvh.build_ms;
+    }
     if ((rc = upload(s->d_materials, s->materials.data(), s->materials.size(), s->stream)) != ER_OK) return rc;
 
     // textures: one float pool + a table
@@ -486,7 +521,7 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     HIP_TRY(hipEventRecord(u1, s->stream));
 
     float scene_scale = 0;
-    for (int a = 0; a < 3; a++) scene_scale = std::max(scene_scale, std::max(std::fabs(bvh.lo[a]), std::fabs(bvh.hi[a])));
+    for (int a = 0; a < 3; a++) scene_scale = std::max(scene_scale, std::max(std::fabs(bvh_lo[a]), std::fabs(bvh_hi[a])));
     scene_scale = std::max(scene_scale, std::max(std::fabs(s->camera.position.x), std::max(std::fabs(s->camera.position.y), std::fabs(s->camera.position.z))));
 
     DevScene& D = s->dev;
@@ -497,9 +532,9 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     D.tri_base_pieces = (uint32_t)n8_pieces;
     D.tri_attr = s->d_attr.p;
     D.tri_count = s->tri_count;
-    D.node_count = (uint32_t)bvh.nodes.size();
-    D.prune_margin = bvh.lift_bound + 1e-5f * scene_scale;
-    D.max_lift = bvh.lift_bound;
+    D.node_count = bvh2_nodes;
+    D.prune_margin = lift_bound + 1e-5f * scene_scale;
+    D.max_lift = lift_bound;
     D.scene_scale = scene_scale;
     D.materials = s->d_materials.p;
     D.textures = s->d_textures.p;
@@ -530,14 +565,15 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     (void)hipEventDestroy(u0);
     (void)hipEventDestroy(u1);
 
-    s->accel.node_count = (uint32_t)bvh.nodes8.size();
+    s->accel.node_count = wide_nodes;
     s->accel.node_bytes = sizeof(ErNode8);
-    s->accel.max_depth = bvh.max_depth8;
-    s->accel.leaf_count = bvh.leaf_count;
+    s->accel.max_depth = wide_depth;
+    s->accel.leaf_count = leaf_count;
     s->accel.tri_record_bytes = sizeof(ErTriIsect);
-    s->accel.build_ms = (float)bvh.build_ms;
+    s->accel.build_ms = (float)build_ms;
     s->accel.upload_ms = up_ms;
-    s->accel.lift_bound = bvh.lift_bound;
+    s->accel.lift_bound = lift_bound;
+    s->accel.builder = built ? 1u : 0u;
     s->begun = true;
     return ER_OK;
 }

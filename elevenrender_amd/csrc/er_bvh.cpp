@@ -175,7 +175,7 @@ inline float area3(const float* lo, const float* hi) {
 }
 }  // namespace
 
-static void collapse_bvh8(ErBvhBuild* out) {
+void er_collapse_bvh8(ErBvhBuild* out) {
     out->nodes8.clear();
     out->max_depth8 = 0;
     if (out->nodes.empty()) return;
@@ -508,6 +508,6 @@ void er_build_bvh(const float* vertices, const float* normals, uint32_t tri_coun
     }
     out->slot_to_tri.resize(tri_count);
     for (uint32_t i = 0; i < tri_count; i++) out->slot_to_tri[i] = B.prims[i].id;
-    collapse_bvh8(out);
+    er_collapse_bvh8(out);
     out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }

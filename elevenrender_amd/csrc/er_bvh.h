@@ -78,5 +78,9 @@ struct ErBvhBuild {
     double build_ms = 0;
 };
 
+// collapse of ErBvhBuild::nodes (root = node 0) into nodes8; re-orders slot_to_tri and the binary tree's leaf
+// references into the wide tree's leaf order.  Called by er_build_bvh; public for the device builder.
+void er_collapse_bvh8(ErBvhBuild* out);
+
 // vertices/normals: [tri][3][3].  threads <= 0 -> hardware concurrency.
 void er_build_bvh(const float* vertices, const float* normals, uint32_t tri_count, int threads, ErBvhBuild* out);

@@ -1,0 +1,34 @@
+// er_gpu_build.h -- device-side BVH builder (er_gpu_build.hip), SURVEY.md 8(f) rank 1.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <string>
+
+#include "er_bvh.h"
+
+// Binary tree only: builds ErBvhBuild::nodes, slot_to_tri, tri_lift, bounds, lift_bound, leaf_count, max_depth on HIP
+// device `device` from host arrays [n][3][3] and downloads them; the caller then runs er_collapse_bvh8 on the host.
+// Returns 0 on success; > 0 = the device builder declines (too few triangles, tree deeper than the traversal stack
+// bound) and the caller should use er_build_bvh; < 0 = HIP error.  `err` gets the reason.
+int er_gpu_build_binary(const float* vertices, const float* normals, uint32_t n, int device, ErBvhBuild* out, std::string& err);
+
+// Whole structure on the device: binary tree, SAH-optimal collapse into 8-wide nodes, final slot order and the
+// triangle records, in the buffers er_render_begin hands to the kernels.  Nothing but a few counters comes back.
+struct ErGpuSceneArrays {        // host arrays of the scene, per original triangle
+    const float* vertices;       // [n][3][3]
+    const float* normals;        // [n][3][3]
+    const float* tangents;       // [n][3][3]
+    const float* uvs;            // [n][3][2]
+    const float* tangent_sign;   // [n]
+    const int32_t* material_id;  // [n]
+};
+struct ErGpuBvhDevice {
+    float4* nodes = nullptr;     // binary tree, nodes_f4 float4 (ownership passes to the caller: hipFree)
+    float4* geom = nullptr;      // wide nodes + padding (n8_pieces float4) followed by (n + 1) triangle records
+    float4* attr = nullptr;      // attribute records, attr_f4 float4
+    size_t nodes_f4 = 0, geom_f4 = 0, attr_f4 = 0, n8_pieces = 0;
+    uint32_t nodes8_count = 0, max_depth8 = 0, max_depth2 = 0, leaf_count = 0;
+    float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, lift_bound = 0;
+    double build_ms = 0;
+};
+int er_gpu_build_device(const ErGpuSceneArrays& arrays, uint32_t n, int device, ErGpuBvhDevice* out, std::string& err);

@@ -119,6 +119,9 @@ typedef struct ErSceneDesc {
 #define ER_FLAG_FUSED        16u  /* persistent waves, lane-asynchronous: trace steps + batched shading, no barrier */
 #define ER_FLAG_WAVEFRONT    32u  /* one trace + one shade launch per bounce over compacted ray queues */
 #define ER_FLAG_PROFILE      8u   /* bracket every trace / shade launch with HIP events (see er_get_profile) */
+#define ER_FLAG_GPU_BUILD    64u  /* build the acceleration structure on the GPU (linear BVH: several times faster to
+                                     build, slower to trace; falls back to the host SAH build if the tree would be too
+                                     deep).  Images do not depend on the builder. */
 
 /* reference RenderParameters (src/kernel.h:51-69) + what the MI355X build adds. */
 typedef struct ErRenderParams {
@@ -215,6 +218,7 @@ typedef struct ErAccelInfo {
     uint32_t tri_record_bytes;         /* bytes fetched per triangle test */
     float build_ms, upload_ms;
     float lift_bound;                  /* global bound on |shadingPosition - geomPosition| */
+    uint32_t builder;                  /* 0 = host binned-SAH build, 1 = device linear-BVH build (ER_FLAG_GPU_BUILD) */
 } ErAccelInfo;
 int er_accel_info(ErScene* scene, ErAccelInfo* out);
 

@@ -311,3 +311,6 @@ def test_c4_full_size_properties():
     idx = erdist.tile_pixel_index(erdist.owned_tiles(11, 96, 3840, 2160), 3840, 2160)
     idx = idx[idx >= 0]
     assert (w["beauty"].reshape(-1, 4)[idx].view(np.uint32) == a["beauty"].reshape(-1, 4)[idx].view(np.uint32)).all()
+    # the same window through a tree built on the device (er_gpu_build.hip): only exact-tie pixels may differ
+    g = gpu_render(sc, 2, max_bounces=8, rank=11, world=96, flags=abi.FLAG_GPU_BUILD)
+    assert (g["beauty"].view(np.uint32) != w["beauty"].view(np.uint32)).any(-1).sum() <= 1e-4 * len(idx)
