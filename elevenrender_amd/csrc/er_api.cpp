@@ -492,8 +492,10 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         uint32_t cus = (uint32_t)prop.multiProcessorCount;
-        s->trace_blocks = cus * 16;   // persistent waves (LDS 8 KB/wave would admit 20; 16 measured best)
-        s->shade_blocks = cus * 8;
+        // persistent waves per CU, tuned together with the pools (the launches of different pools share the CUs):
+        // trace 8/10/12/14/16 -> 1016/1046/1043/1022/1042 Msamples/s at shade 5; shade 4/5/6/7 -> 1019/1051/1012/987
+        s->trace_blocks = cus * 12;
+        s->shade_blocks = cus * 5;
         if (const char* e = getenv("ER_TRACE_WAVES_PER_CU")) s->trace_blocks = cus * (uint32_t)std::max(1, atoi(e));   // tuning knob
         if (const char* e = getenv("ER_SHADE_WAVES_PER_CU")) s->shade_blocks = cus * (uint32_t)std::max(1, atoi(e));
         const size_t spill_per_pool = (size_t)s->trace_blocks * ER_BVH_MAX_DEPTH * 64;

@@ -102,8 +102,11 @@ __global__ __launch_bounds__(64) void er_wf_begin(DevScene S, WfState W, uint32_
 // queue (one global atomic per chunk) -- lanes never wait for the slowest ray of a 64-ray batch.
 #define WF_REFILL_MIN 16   // default; ER_TRACE_REFILL_MIN overrides it at run time (tuning knob; flat from 4 to 32)
 
+#ifndef WF_TRACE_WAVES
+#define WF_TRACE_WAVES 4
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_t parity, uint32_t refill_min) {
+__global__ __launch_bounds__(64, WF_TRACE_WAVES) void er_wf_trace(DevScene S, WfState W, uint32_t parity, uint32_t refill_min) {
     __shared__ uint2 s_stack[WF_LDS_STACK * 64];
     const int lane = threadIdx.x;
     uint2* stack = s_stack + lane;
@@ -227,8 +230,12 @@ __global__ __launch_bounds__(64) void er_wf_trace(DevScene S, WfState W, uint32_
 }
 
 // ---- shade: one bounce-loop step per active slot (src/kernel.cpp:508-645) ----
+// Compiled for 4 waves per SIMD (128 VGPRs, ~77 spilled) although only 5 shade waves per CU are launched: the three
+// slot pools run trace and shade launches side by side, and a shade wave that holds 128 instead of 200 registers
+// leaves room for one more trace wave on its SIMD.  Measured on C2 (trace 12 / shade 5 waves per CU): 1045 Msamples/s
+// against 962 with the unspilled 200-register build; a 96-register trace kernel (5 per SIMD) loses 10 %.
 #ifndef WF_SHADE_WAVES
-#define WF_SHADE_WAVES 2
+#define WF_SHADE_WAVES 4
 #endif
 template <bool COUNT>
 __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, WfState W, uint32_t parity) {
