@@ -6,14 +6,10 @@
 
 #include "er_bvh.h"
 
-// Binary tree only: builds ErBvhBuild::nodes, slot_to_tri, tri_lift, bounds, lift_bound, leaf_count, max_depth on HIP
-// device `device` from host arrays [n][3][3] and downloads them; the caller then runs er_collapse_bvh8 on the host.
-// Returns 0 on success; > 0 = the device builder declines (too few triangles, tree deeper than the traversal stack
-// bound) and the caller should use er_build_bvh; < 0 = HIP error.  `err` gets the reason.
-int er_gpu_build_binary(const float* vertices, const float* normals, uint32_t n, int device, ErBvhBuild* out, std::string& err);
-
 // Whole structure on the device: binary tree, SAH-optimal collapse into 8-wide nodes, final slot order and the
 // triangle records, in the buffers er_render_begin hands to the kernels.  Nothing but a few counters comes back.
+// Returns 0 on success; > 0 = the device builder declines (too few triangles, tree deeper than the traversal stack
+// bound) and the caller should use er_build_bvh; < 0 = HIP error.  `err` gets the reason.
 struct ErGpuSceneArrays {        // host arrays of the scene, per original triangle
     const float* vertices;       // [n][3][3]
     const float* normals;        // [n][3][3]

@@ -579,28 +579,6 @@ struct GpuBuild {
 
 }  // namespace
 
-int er_gpu_build_binary(const float* vertices, const float* normals, uint32_t n, int device, ErBvhBuild* out, std::string& err) {
-    auto t0 = std::chrono::steady_clock::now();
-    if (n <= ER_BVH_LEAF_MAX) { err = "too few triangles for the device builder"; return 1; }
-    GpuBuild B;
-    int rc = B.binary(vertices, normals, n, device, err);
-    if (rc != 0) return rc;
-    out->nodes.resize(B.n_inner);
-    out->slot_to_tri.resize(n);
-    out->tri_lift.resize(n);
-    GB_OK(hipMemcpyAsync(out->nodes.data(), B.d_nodes.p, (size_t)B.n_inner * sizeof(ErNode), hipMemcpyDeviceToHost, B.st));
-    GB_OK(hipMemcpyAsync(out->slot_to_tri.data(), B.d_ids2.p, (size_t)n * 4, hipMemcpyDeviceToHost, B.st));
-    GB_OK(hipMemcpyAsync(out->tri_lift.data(), B.d_lift.p, (size_t)n * 4, hipMemcpyDeviceToHost, B.st));
-    GB_OK(hipStreamSynchronize(B.st));
-    const ErNode& r = out->nodes[0];     // scene bounds = the root's two child boxes
-    for (int a = 0; a < 3; a++) { out->lo[a] = std::fmin(r.lo0[a], r.lo1[a]); out->hi[a] = std::fmax(r.hi0[a], r.hi1[a]); }
-    out->lift_bound = B.lift_bound();
-    out->leaf_count = B.g[9];
-    out->max_depth = B.g[8] + 1;
-    out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return 0;
-}
-
 int er_gpu_build_device(const ErGpuSceneArrays& a, uint32_t n, int device, ErGpuBvhDevice* out, std::string& err) {
     auto t0 = std::chrono::steady_clock::now();
     if (n <= ER_BVH_LEAF_MAX) { err = "too few triangles for the device builder"; return 1; }
