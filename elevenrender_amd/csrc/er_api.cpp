@@ -797,6 +797,29 @@ int er_accel_info(ErScene* s, ErAccelInfo* out) {
 // ---- host-only debug hook (include/eleven_hip_debug.h) ----
 #include "../../include/eleven_hip_debug.h"
 
+extern "C" int er_debug_closest_hit(ErScene* s, const float* origins, const float* dirs, uint32_t n, int32_t* tri_ids, float* positions, float* distances) {
+    if (!s || !origins || !dirs || !tri_ids || !positions || !distances) return fail(ER_ERR_INVALID_ARG, "er_debug_closest_hit: NULL argument");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if (!s->begun) return fail(ER_ERR_STATE, "er_debug_closest_hit: er_render_begin has not succeeded");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf<float> d_o, d_d, d_pos, d_dist;
+    DevBuf<int32_t> d_tri;
+    int rc;
+    if ((rc = upload(d_o, origins, (size_t)n * 3, s->stream)) != ER_OK) return rc;
+    if ((rc = upload(d_d, dirs, (size_t)n * 3, s->stream)) != ER_OK) return rc;
+    if ((rc = upload(d_pos, (const float*)nullptr, (size_t)n * 3, s->stream)) != ER_OK) return rc;
+    if ((rc = upload(d_dist, (const float*)nullptr, (size_t)n, s->stream)) != ER_OK) return rc;
+    if ((rc = upload(d_tri, (const int32_t*)nullptr, (size_t)n, s->stream)) != ER_OK) return rc;
+    er_launch_debug_hit(s->dev, d_o.p, d_d.p, n, d_tri.p, d_pos.p, d_dist.p, s->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(tri_ids, d_tri.p, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(positions, d_pos.p, (size_t)n * 12, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipMemcpyAsync(distances, d_dist.p, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    d_o.release(); d_d.release(); d_pos.release(); d_dist.release(); d_tri.release();
+    return ER_OK;
+}
+
 extern "C" int er_debug_cdf_search(const float* cdf, int length, const float* values, int32_t* out, int count) {
     if (!cdf || !values || !out || length <= 0) return fail(ER_ERR_INVALID_ARG, "er_debug_cdf_search: bad argument");
     std::vector<uint32_t> guide;

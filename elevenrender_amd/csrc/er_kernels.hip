@@ -191,6 +191,33 @@ __global__ __launch_bounds__(64) void er_unpack_kernel(DevScene S, const uint32_
         S.passes[(size_t)pass * S.x_res * S.y_res + (size_t)py * S.x_res + px] = src[(size_t)blockIdx.x * 64 + lane];
 }
 
+// ---- debug: closest hit of arbitrary rays through the exact routine (include/eleven_hip_debug.h) ----
+__global__ __launch_bounds__(64) void er_debug_hit_kernel(DevScene S, const float* __restrict__ o, const float* __restrict__ d, uint32_t n,
+                                                           int32_t* __restrict__ tri_out, float* __restrict__ pos_out, float* __restrict__ dist_out) {
+    __shared__ int s_stack[ER_STACK * 64];
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    Ray ray;
+    ray.o = f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+    ray.d = f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    float dist = 0;
+    unsigned cn = 0, ct = 0;
+    const int slot = trace<false, false>(S, s_stack + threadIdx.x, ray, -1, __builtin_inff(), dist, cn, ct);
+    tri_out[i] = -1;
+    pos_out[3 * i] = pos_out[3 * i + 1] = pos_out[3 * i + 2] = 0.0f;
+    dist_out[i] = dist;
+    if (slot >= 0) {
+        HitFull h;
+        full_hit(S, (uint32_t)slot, ray, h);
+        tri_out[i] = __builtin_bit_cast(int, S.tri_isect[(size_t)slot * 3].w);
+        pos_out[3 * i] = h.position.x; pos_out[3 * i + 1] = h.position.y; pos_out[3 * i + 2] = h.position.z;
+    }
+}
+void er_launch_debug_hit(const DevScene& S, const float* o, const float* d, uint32_t n, int32_t* tri, float* pos, float* dist, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(er_debug_hit_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, S, o, d, n, tri, pos, dist);
+}
+
 void er_launch_setup(const DevScene& S, hipStream_t stream) {
     uint32_t npx = S.x_res * S.y_res;
     if (npx == 0) return;

@@ -129,6 +129,18 @@ class RenderingManager:
         abi.check(self.lib.er_accel_info(self.handle, C.byref(a)))
         return {n: getattr(a, n) for n, _ in abi.ErAccelInfo._fields_}
 
+    def debug_closest_hit(self, origins, dirs):
+        """include/eleven_hip_debug.h: (triangle id, Hit.position, distance) of arbitrary rays through the exact routine."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = len(o)
+        tri = np.empty(n, np.int32)
+        pos = np.empty((n, 3), np.float32)
+        dist = np.empty(n, np.float32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        abi.check(self.lib.er_debug_closest_hit(self.handle, fp(o), fp(d), n, tri.ctypes.data_as(C.POINTER(C.c_int32)), fp(pos), fp(dist)))
+        return tri, pos, dist
+
     def owned_count(self, rank):
         v = C.c_uint64()
         abi.check(self.lib.er_owned_count(self.handle, rank, C.byref(v)))

@@ -27,6 +27,13 @@ int er_debug_bvh_check(const float* vertices, const float* normals, uint32_t tri
  * HDRI::binarySearch, reference src/HDRI.cpp:85-98) on the host for `count` values. */
 int er_debug_cdf_search(const float* cdf, int length, const float* values, int32_t* out, int count);
 
+/* Closest hit of `n` arbitrary rays (origins/dirs [n][3]; directions taken as given) through the library's exact
+ * traversal routine on the GPU, under the reference's metric (src/BVH.cpp:105-120): original triangle id (-1 = miss),
+ * Hit.position and |Hit.position - origin|.  Needs a scene on which er_render_begin has succeeded.  Used by the
+ * function-level parity test against the oracle's throwRay. */
+struct ErScene;
+int er_debug_closest_hit(struct ErScene* scene, const float* origins, const float* dirs, uint32_t n, int32_t* tri_ids, float* positions, float* distances);
+
 #ifdef __cplusplus
 }
 #endif
