@@ -11,8 +11,8 @@
 //   RenderingManager::start_rendering / get_pass /       same methods (src/Managers.h:41-66, Managers.cpp:211-302)
 //     get_render_info
 //
-// Only what the per-sample path consumes is mirrored; commands, TCP, OBJ loading and denoising stay the
-// reference's.  Errors surface as std::runtime_error carrying er_last_error(); nothing falls back to the CPU.
+// Only what the per-sample path consumes is mirrored (OBJ ingest: eleven_obj.hpp beside this file); commands, TCP and
+// denoising stay the reference's.  Errors surface as std::runtime_error carrying er_last_error(); nothing falls back to the CPU.
 #pragma once
 #include <algorithm>
 #include <cctype>

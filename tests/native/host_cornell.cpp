@@ -1,11 +1,16 @@
 // host_cornell.cpp -- drives the C++ host mirror (elevenrender_amd/host/eleven_host.hpp) the way the reference's
 // CommandManager drives its Scene/RenderingManager: build the Cornell scene of scenes.cornell(), render, print
 // every beauty texel's bits folded into a checksum.  tests/test_gpu_host_cpp.py compares it with the Python path.
+// With a third argument the geometry comes from that OBJ file through eleven::load_obj instead (the materials
+// keep their names, as after the reference's load_object + pair_materials).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
+#include <fstream>
+
 #include "../../elevenrender_amd/host/eleven_host.hpp"
+#include "../../elevenrender_amd/host/eleven_obj.hpp"
 
 using namespace eleven;
 
@@ -37,6 +42,11 @@ int main(int argc, char** argv) {
     light.name = "light"; light.emission = Vector3(5, 5, 5);
     scene.addMaterial(red); scene.addMaterial(green); scene.addMaterial(light);
     MeshObject box;
+    if (argc > 3) {
+        std::ifstream in(argv[3]);
+        if (!in) { fprintf(stderr, "error: cannot open %s\n", argv[3]); return 1; }
+        for (MeshObject& mo : load_obj(in)) scene.addMeshObject(mo);
+    } else {
     const float x0 = -1, x1 = 1, y0 = -1, y1 = 1, z0 = 2, z1 = 4, l = 0.4f, yl = 0.995f;
     quad(box, {x0, y0, z0}, {x0, y0, z1}, {x1, y0, z1}, {x1, y0, z0}, "default");
     quad(box, {x0, y1, z0}, {x1, y1, z0}, {x1, y1, z1}, {x0, y1, z1}, "default");
@@ -45,6 +55,7 @@ int main(int argc, char** argv) {
     quad(box, {x1, y0, z0}, {x1, y0, z1}, {x1, y1, z1}, {x1, y1, z0}, "green");
     quad(box, {-l, yl, 3 - l}, {l, yl, 3 - l}, {l, yl, 3 + l}, {-l, yl, 3 + l}, "light");
     scene.addMeshObject(box);
+    }
     scene.pair_materials();
     scene.camera.position = Vector3(0, 0, -1.5f);
     scene.x_res = res; scene.y_res = res;

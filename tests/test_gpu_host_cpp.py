@@ -16,7 +16,8 @@ NATIVE = os.path.join(ROOT, "tests", "native")
 def build(name):
     exe = os.path.join(NATIVE, name)
     src = exe + ".cpp"
-    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+    hdrs = [os.path.join(ROOT, "elevenrender_amd", "host", h) for h in ("eleven_host.hpp", "eleven_obj.hpp")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O1", "-std=c++17", src, "-o", exe, "-L", os.path.join(ROOT, "elevenrender_amd"),
                                "-leleven_hip", "-Wl,-rpath,$ORIGIN/../../elevenrender_amd"])
     return exe
@@ -36,6 +37,24 @@ def test_cpp_host_mirror_matches_python_mirror():
     assert "samples 6" in out
     rm = render.RenderingManager()
     rm.start_rendering(scenes.cornell(48, 48))
+    rm.render(5)
+    img = rm.get_pass("beauty")
+    rm.close()
+    assert f"fnv1a {fnv1a(img):016x}" in out, out
+
+
+@pytest.mark.gpu
+def test_obj_file_through_cpp_host_gives_the_same_image(tmp_path):
+    """BASELINE config 1 names a Cornell-box .obj: the box written as OBJ text, read by eleven::load_obj
+    (elevenrender_amd/host/eleven_obj.hpp) and rendered through the C++ host mirror equals the generated scene."""
+    from test_obj_cpu import write_obj
+    sc = scenes.cornell(48, 48)
+    path = str(tmp_path / "cornell.obj")
+    write_obj(path, sc, names=["default", "red", "green", "light"])
+    exe = build("host_cornell")
+    out = subprocess.check_output([exe, "48", "5", path], text=True)
+    rm = render.RenderingManager()
+    rm.start_rendering(sc)
     rm.render(5)
     img = rm.get_pass("beauty")
     rm.close()
