@@ -117,6 +117,7 @@ SYMBOLS = {
     "er_get_counters": (C.c_int, [_P, C.POINTER(ErCounters)]),
     "er_accel_info": (C.c_int, [_P, C.POINTER(ErAccelInfo)]),
     "er_get_profile": (C.c_int, [_P, C.POINTER(ErProfile)]),
+    "er_denoise": (C.c_int, [_P, C.c_uint32, C.c_float]),
     "er_debug_closest_hit": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_float),
                                        C.POINTER(C.c_float)]),
 }

@@ -716,6 +716,38 @@ int er_read_pass(ErScene* s, int pass, float* dst) {
     size_t npx = (size_t)s->x_res * s->y_res;
     return read_back(s, s->d_passes.p + (size_t)pass * npx, dst, npx * sizeof(float4), "er_read_pass");
 }
+int er_denoise(ErScene* s, uint32_t levels, float colour_sigma) {
+    if (!s) return fail(ER_ERR_INVALID_ARG, "er_denoise: NULL scene");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if (!s->begun) return fail(ER_ERR_STATE, "er_denoise: er_render_begin has not succeeded");
+    if (s->params.world > 1) return fail(ER_ERR_STATE, "er_denoise: the frame is sharded over several ranks; gather it first");
+    if (levels == 0) levels = 5;
+    if (levels > 8) return fail(ER_ERR_INVALID_ARG, "er_denoise: at most 8 levels");
+    if (!(colour_sigma >= 0)) return fail(ER_ERR_INVALID_ARG, "er_denoise: colour_sigma must be >= 0");
+    if (colour_sigma == 0) colour_sigma = 1.0f;
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t npx = (size_t)s->x_res * s->y_res;
+    DevBuf<float4> tmp;
+    int rc;
+    if ((rc = upload(tmp, (const void*)nullptr, npx, s->stream)) != ER_OK) return rc;
+    const float4* beauty = s->d_passes.p + (size_t)ER_PASS_BEAUTY * npx;
+    const float4* normal = s->d_passes.p + (size_t)ER_PASS_NORMAL * npx;
+    float4* out = s->d_passes.p + (size_t)ER_PASS_DENOISE * npx;
+    // ping-pong so that the last level lands in the DENOISE plane
+    const float4* src = beauty;
+    for (uint32_t k = 0; k < levels; k++) {
+        float4* dst = ((levels - 1 - k) & 1u) ? tmp.p : out;
+        // the colour edge-stop tightens with the level, as the residual noise shrinks
+        const float kc = 1.0f / (colour_sigma * colour_sigma) * (float)(1u << k);
+        er_launch_atrous(src, normal, dst, (int)s->x_res, (int)s->y_res, 1 << k, kc, s->stream);
+        src = dst;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    tmp.release();
+    return ER_OK;
+}
+
 int er_read_samples(ErScene* s, uint32_t* dst) {
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_read_samples: NULL scene");
     return read_back(s, s->d_samples.p, dst, (size_t)s->x_res * s->y_res * 4, "er_read_samples");

@@ -6,6 +6,7 @@
 struct DevScene;
 
 void er_launch_setup(const DevScene& S, hipStream_t stream);
+void er_launch_atrous(const float4* src, const float4* normal, float4* dst, int w, int h, int step, float kc, hipStream_t stream);
 void er_launch_debug_hit(const DevScene& S, const float* o, const float* d, uint32_t n, int32_t* tri, float* pos, float* dist, hipStream_t stream);
 void er_launch_render(const DevScene& S, uint32_t n_samples, bool count, hipStream_t stream);
 void er_launch_pack(const DevScene& S, const uint32_t* tiles, uint32_t ntiles, int pass, void* dst, hipStream_t stream);

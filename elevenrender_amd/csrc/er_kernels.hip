@@ -228,6 +228,41 @@ void er_launch_render(const DevScene& S, uint32_t n_samples, bool count, hipStre
     if (count) hipLaunchKernelGGL(er_render_kernel<true>, dim3(S.owned_tile_count), dim3(64), 0, stream, S, n_samples);
     else hipLaunchKernelGGL(er_render_kernel<false>, dim3(S.owned_tile_count), dim3(64), 0, stream, S, n_samples);
 }
+// ---- denoise: edge-avoiding a-trous wavelet filter of the BEAUTY plane, guided by colour and
+// by the first-bounce NORMAL plane, into the DENOISE plane that the reference allocates but never writes (reference
+// src/kernel.cpp:604; its host-side `get_pass denoise` calls OIDN, src/Managers.cpp:319-343, a neural filter that is
+// not on this path and has no arithmetic to match).  One launch per level; level k taps a 5x5 B3-spline stencil with
+// holes of 2^k pixels (Dammertz et al. 2010).  Edge-stopping weights are rational -- w = 1 / (1 + kc |dc|^2) and
+// max(0, n.n')^2 -- so the filter is plain IEEE arithmetic (tests/test_gpu_denoise.py replays it in numpy, bit for bit).
+__global__ __launch_bounds__(256) void er_atrous_kernel(const float4* __restrict__ src, const float4* __restrict__ normal, float4* __restrict__ dst,
+                                                         int w, int h, int step, float kc) {
+    const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+    if (x >= w || y >= h) return;
+    const float kernel[5] = {1.0f / 16.0f, 1.0f / 4.0f, 3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
+    const float4 c = src[(size_t)y * w + x], n = normal[(size_t)y * w + x];
+    float sx = 0, sy = 0, sz = 0, sw = 0;
+    for (int j = -2; j <= 2; j++)
+        for (int i = -2; i <= 2; i++) {
+            int qx = x + i * step, qy = y + j * step;
+            qx = qx < 0 ? 0 : (qx >= w ? w - 1 : qx);
+            qy = qy < 0 ? 0 : (qy >= h ? h - 1 : qy);
+            const float4 cq = src[(size_t)qy * w + qx], nq = normal[(size_t)qy * w + qx];
+            const float dx = c.x - cq.x, dy = c.y - cq.y, dz = c.z - cq.z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            const float wc = 1.0f / (1.0f + kc * d2);
+            float nd = n.x * nq.x + n.y * nq.y + n.z * nq.z;
+            // (pixels whose paths hit nothing have a zero normal: they only blend with each other)
+            const bool none = (n.x == 0.0f && n.y == 0.0f && n.z == 0.0f), noneq = (nq.x == 0.0f && nq.y == 0.0f && nq.z == 0.0f);
+            nd = (none && noneq) ? 1.0f : (nd < 0.0f ? 0.0f : nd);
+            const float wgt = kernel[i + 2] * kernel[j + 2] * wc * (nd * nd);
+            sx = sx + cq.x * wgt; sy = sy + cq.y * wgt; sz = sz + cq.z * wgt; sw = sw + wgt;
+        }
+    dst[(size_t)y * w + x] = make_float4(sx / sw, sy / sw, sz / sw, c.w);
+}
+void er_launch_atrous(const float4* src, const float4* normal, float4* dst, int w, int h, int step, float kc, hipStream_t stream) {
+    hipLaunchKernelGGL(er_atrous_kernel, dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, stream, src, normal, dst, w, h, step, kc);
+}
+
 void er_launch_pack(const DevScene& S, const uint32_t* tiles, uint32_t ntiles, int pass, void* dst, hipStream_t stream) {
     if (ntiles == 0) return;
     hipLaunchKernelGGL(er_pack_kernel, dim3(ntiles), dim3(64), 0, stream, S, tiles, pass, (float4*)dst);

@@ -11,8 +11,8 @@
 //   RenderingManager::start_rendering / get_pass /       same methods (src/Managers.h:41-66, Managers.cpp:211-302)
 //     get_render_info
 //
-// Only what the per-sample path consumes is mirrored (OBJ ingest: eleven_obj.hpp beside this file); commands, TCP and
-// denoising stay the reference's.  Errors surface as std::runtime_error carrying er_last_error(); nothing falls back to the CPU.
+// Only what the per-sample path consumes is mirrored (OBJ ingest: eleven_obj.hpp beside this file; denoise(): the
+// library's own filter in place of DenoiseManager's OIDN call); commands and TCP stay the reference's.  Errors surface as std::runtime_error carrying er_last_error(); nothing falls back to the CPU.
 #pragma once
 #include <algorithm>
 #include <cctype>
@@ -196,6 +196,8 @@ public:
         check(er_read_pass(er_, parsePass(pass), out.data()));
         return out;
     }
+    // DenoiseManager::denoise (src/Managers.cpp:319-343) called OIDN on the host; here the device fills the DENOISE plane
+    void denoise(unsigned levels = 0, float colour_sigma = 0) { check(er_denoise(er_, levels, colour_sigma)); }
     RenderInfo get_render_info() {   // src/Managers.cpp:211-232
         RenderInfo i;
         check(er_samples_done(er_, &i.samples));

@@ -104,6 +104,10 @@ class RenderingManager:
         abi.check(self.lib.er_samples_done(self.handle, C.byref(v)))
         return RenderInfo(samples=v.value)
 
+    def denoise(self, levels=0, colour_sigma=0.0):
+        """Fill the DENOISE plane from BEAUTY + NORMAL (er_denoise); get_pass("denoise") then returns it."""
+        abi.check(self.lib.er_denoise(self.handle, levels, colour_sigma))
+
     def read_samples(self):
         out = np.empty(self.scene.x_res * self.scene.y_res, np.uint32)
         abi.check(self.lib.er_read_samples(self.handle, out.ctypes.data_as(C.POINTER(C.c_uint32))))

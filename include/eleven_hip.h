@@ -184,7 +184,14 @@ int er_samples_done(ErScene* scene, uint32_t* out);
 /* Copies one pass plane (x_res*y_res*4 floats, RGBA, row-major, idx = y*x_res + x) to host memory.
  * With world > 1 only owned pixels are valid; others are left at the setup value (0,0,0,1). */
 int er_read_pass(ErScene* scene, int pass, float* dst_rgba);
-int er_read_samples(ErScene* scene, uint32_t* dst);     /* x_res*y_res */
+int er_read_samples(ErScene* scene, uint32_t* dst);
+
+/* Fills the DENOISE plane (which renderingKernel never writes, src/kernel.cpp:604) with an edge-avoiding a-trous
+ * wavelet filter of the current BEAUTY plane, guided by colour and by the NORMAL plane: `levels` passes (1..8, 0 -> 5)
+ * with stencil holes of 1, 2, 4, ... pixels; colour_sigma > 0 scales the colour edge-stop (0 -> 1).  Stands in for the
+ * reference's host-side OIDN call behind `get_pass denoise` (src/Managers.cpp:319-343, CommandManager.cpp:265-274) --
+ * a different filter: no parity claim.  Single-GPU (world 1) only. */
+int er_denoise(ErScene* scene, uint32_t levels, float colour_sigma);     /* x_res*y_res */
 int er_read_rng(ErScene* scene, uint32_t* dst);         /* x_res*y_res */
 
 /* Multi-GPU framebuffer combine helpers (the collective itself is done by the host with
