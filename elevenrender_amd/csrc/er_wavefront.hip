@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64, WF_TRACE_WAVES) void er_wf_trace(DevScene S, Wf
 }
 
 // ---- shade: one bounce-loop step per active slot (src/kernel.cpp:508-645) ----
-// Compiled for 4 waves per SIMD (128 VGPRs, ~77 spilled) although only 5 shade waves per CU are launched: the three
+// Compiled for 4 waves per SIMD (128 VGPRs, 118 spilled) although only 5 shade waves per CU are launched: the three
 // slot pools run trace and shade launches side by side, and a shade wave that holds 128 instead of 200 registers
 // leaves room for one more trace wave on its SIMD.  Measured on C2 (trace 12 / shade 5 waves per CU): 1045 Msamples/s
 // against 962 with the unspilled 200-register build; a 96-register trace kernel (5 per SIMD) loses 10 %.
