@@ -348,3 +348,25 @@ def test_closest_hit_function_level(oracle_mod):
             d = np.where(hit[:, None], nd, d)
         rm.close()
         orc.close()
+
+
+@pytest.mark.parametrize("flags", [abi.FLAG_WAVEFRONT, abi.FLAG_FUSED])
+def test_read_back_during_asynchronous_rendering_is_a_sample_boundary_snapshot(flags):
+    """The reference reads passes on a second queue while the render thread enqueues samples, unsynchronised
+    (src/Managers.cpp:287-302: torn reads).  Here er_read_pass is ordered after everything enqueued so far -- including
+    the wavefront schedule's slot pools on their own streams -- so a read issued right after an asynchronous
+    er_render_samples returns exactly the state after those samples."""
+    sc = scenes.soup(30000, 200, 120, seed=19, hdri_size=(128, 64))
+    want3 = gpu_render(sc, 3, max_bounces=8, flags=flags)
+    want8 = gpu_render(sc, 8, max_bounces=8, flags=flags)
+    rm = render.RenderingManager(render.RenderParameters(max_bounces=8, flags=flags))
+    rm.start_rendering(sc)
+    rm.render(3, blocking=False)
+    got3 = rm.get_pass("beauty")                  # no er_wait in between
+    assert rm.get_render_info().samples == 4
+    rm.render(5, blocking=False)
+    got8 = rm.get_pass("beauty")
+    rm.wait()
+    rm.close()
+    assert (got3.view(np.uint32) == want3["beauty"].view(np.uint32)).all()
+    assert (got8.view(np.uint32) == want8["beauty"].view(np.uint32)).all()
