@@ -1,16 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- Msamples/s of the per-sample path-tracing hot path on MI355X.
 
-Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): synthetic 1M random-triangle soup +
-2048x1024 procedural sky HDRI, 1920x1080, max_bounces 8, seed 12345.  A STEP is one sample
-pass (one renderingKernel per pixel, reference src/kernel.cpp:689-700); the 256 spp of the
-config are 256 such steps.  `value` = executed bounce-loop iterations (the reference's
-`for (i...)` at src/kernel.cpp:508, counted on the device) per second, whole job, scene and
-framebuffers resident in HBM when the timed region starts.
+Default workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): synthetic 1M random-triangle soup + 2048x1024
+procedural sky HDRI, 1920x1080, max_bounces 8, seed 12345.  `--config C1|C4|C5` selects the other BASELINE scenes
+(their numbers are reported with the same fields; `config.workload` names what ran).  A STEP is one sample pass (one
+renderingKernel per pixel, reference src/kernel.cpp:689-700); the 256 spp of the config are 256 such steps.
+`value` = executed bounce-loop iterations (the reference's `for (i...)` at src/kernel.cpp:508, counted on the device)
+per second, whole job, scene and framebuffers resident in HBM when the timed region starts.
 
-With --gpus N the frame's 8x8 pixel tiles are sharded over N ranks (one process per GPU,
-launched by torch.distributed.run); there is no collective in the timed region -- the RCCL
-framebuffer gather happens once after it and is reported as readback_ms.
+Roofline (dominant kernel: the traversal).  Algorithmic bytes follow SURVEY.md 8(d): 64 B per node visit + 36 B per
+triangle test, event counts from an instrumented replay of the same samples.
+  roofline.achieved = ALL traversal bytes of the timed region / the wall time of the timed region (nothing is scaled by
+      a concurrency factor: the slot pools' launches overlap each other and the shade launches, so this is a lower
+      bound on the rate "during traversal");
+  roofline.trace_phase = the same bytes / the summed duration of the trace launches in a second pass of the same steps
+      with ONE slot pool on ONE stream, where launches cannot overlap and the division is exact -- the rate while the
+      traversal kernel has the chip to itself;
+  roofline.peak = 8 TB/s (HBM3E spec, MI355X_MICROARCH.md); roofline.peak_measured = a streaming copy / read kernel timed
+      in this job (er_measure_hbm_peak).
+
+With --gpus N the frame's 8x8 pixel tiles are sharded over N ranks (one process per GPU, launched by
+torch.distributed.run); there is no collective in the timed region -- the RCCL framebuffer gather (all five planes,
+through the library's own C++ entry er_gather_pass) happens once after it and is reported as readback_ms.
 
 Prints ONE JSON line on rank 0.
 """
@@ -25,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+PROFILE_TAG = "r02"     # profiles/<tag>_pmc_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
 
 
 def trace_bytes(c):
@@ -49,36 +61,92 @@ def path_bytes(c, hdri_texels):
             + 112 * c["paths"])
 
 
-def cpu_baseline(scene, max_bounces, budget_s=18.0):
-    """The oracle (a port of the reference algorithm: fixed-depth-18 BVH, unordered unpruned
-    traversal) timed on this box's host cores, on a bounded sample of the same workload."""
+def host_cores():
+    """Cores this job may really use: the affinity mask, cut to the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(scene, max_bounces, flags, threads, budget_s=16.0, one_core_budget_s=7.0):
+    """The oracle (a port of the reference algorithm: fixed-depth-18 BVH, unordered unpruned traversal) timed on this
+    box's host cores, on a bounded sample of the same workload: once on `threads` threads, once on ONE."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle
-    cores = max(1, min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 16))   # the GPU box's CPU share for one GPU is 16
-    o = oracle.Oracle(scene, math_mode=oracle.MATH_LIBM, max_bounces=max_bounces, threads=cores)
     W, H = scene.x_res, scene.y_res
 
-    def run_rows(rows):
-        t0 = time.perf_counter()
-        c0 = o.counters()["bounce_samples"]
-        for y in rows:
-            o.render(1, y * W, (y + 1) * W)
-        return time.perf_counter() - t0, o.counters()["bounce_samples"] - c0
+    def leg(nthreads, budget):
+        o = oracle.Oracle(scene, math_mode=oracle.MATH_LIBM, max_bounces=max_bounces, threads=nthreads, flags=flags)
 
-    probe_rows = list(range(H // 16, H, H // 8))[:8]          # 8 rows spread over the frame
-    t_probe, s_probe = run_rows(probe_rows)
-    per_row = t_probe / len(probe_rows)
-    n_rows = int(max(8, min(H - len(probe_rows), budget_s / max(per_row, 1e-6))))
-    stride = max(1, H // n_rows)
-    rows = [y for y in range(stride // 2, H, stride) if y not in probe_rows][:n_rows]
-    t_main, s_main = run_rows(rows)
-    total_rows = len(probe_rows) + len(rows)
-    value = (s_probe + s_main) / (t_probe + t_main) / 1e6
-    build_s = o.build_seconds
-    o.close()
-    return {"value": round(value, 6), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "sample": f"{total_rows} rows x {W} px of the same 1M-tri frame at 1 spp (rows spread over the image), "
-                      f"{t_probe + t_main:.1f} s of work on {cores} threads; reference-BVH build {build_s:.1f} s not timed"}
+        def run_rows(rows):
+            t0 = time.perf_counter()
+            c0 = o.counters()["bounce_samples"]
+            for y in rows:
+                o.render(1, y * W, (y + 1) * W)
+            return time.perf_counter() - t0, o.counters()["bounce_samples"] - c0
+
+        n_probe = max(1, min(8, H // 8))
+        probe_rows = list(range(H // (2 * n_probe), H, max(1, H // n_probe)))[:n_probe]     # rows spread over the frame
+        t_probe, s_probe = run_rows(probe_rows)
+        per_row = t_probe / len(probe_rows)
+        n_rows = int(max(0, min(H - len(probe_rows), (budget - t_probe) / max(per_row, 1e-6))))
+        rows = []
+        if n_rows > 0:
+            stride = max(1, H // n_rows)
+            rows = [y for y in range(stride // 2, H, stride) if y not in probe_rows][:n_rows]
+        t_main, s_main = run_rows(rows) if rows else (0.0, 0)
+        build_s = o.build_seconds
+        o.close()
+        total_rows = len(probe_rows) + len(rows)
+        return (s_probe + s_main) / (t_probe + t_main) / 1e6, total_rows, t_probe + t_main, build_s
+
+    v_all, rows_all, t_all, build_s = leg(threads, budget_s)
+    v_one, rows_one, t_one, _ = leg(1, one_core_budget_s)
+    return {"value": round(v_all, 6), "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"{rows_all} rows x {W} px of the same frame at 1 spp (rows spread over the image), {t_all:.1f} s of work on "
+                      f"{threads} threads (all cores this job may use: affinity mask cut to the cgroup quota; --cpu-threads overrides); "
+                      f"reference-BVH build {build_s:.1f} s not timed",
+            "one_core": {"value": round(v_one, 6), "cores": 1, "sample": f"{rows_one} rows x {W} px, {t_one:.1f} s on 1 thread"}}
+
+
+CONFIGS = {
+    # name: (description, default max_bounces, config spp)
+    "C1": ("Cornell box, 12 triangles, 256x256", 4, 16),
+    "C2": ("1M random-triangle soup + 2048x1024 sky HDRI, 1920x1080", 8, 256),
+    "C4": ("9.68M triangles (10 000 instances of a 968-triangle smooth blob, flattened) + sky HDRI, 3840x2160", 8, 1024),
+    "C5": ("1M-triangle soup, 64 textured materials (192 value-noise textures), 256 point lights, MIS on, 1920x1080", 16, 256),
+}
+
+
+def make_scene(args, scenes, abi):
+    """The BASELINE.json scene `--config` names; returns (scene, extension flags, workload text)."""
+    ext = 0
+    if args.config == "C1":
+        w, h = args.width or 256, args.height or 256
+        sc = scenes.cornell(w, h)
+        what = f"C1: {CONFIGS['C1'][0].replace('256x256', f'{w}x{h}')}"
+    elif args.config == "C2":
+        w, h = args.width or 1920, args.height or 1080
+        sc = scenes.soup(args.tris, w, h, seed=12345)
+        what = f"C2: {args.tris}-triangle random soup + 2048x1024 sky HDRI, {w}x{h}"
+    elif args.config == "C4":
+        w, h = args.width or 3840, args.height or 2160
+        sc = scenes.blob_instances(x_res=w, y_res=h)
+        what = f"C4: {sc.tri_count} triangles (10 000 instances of a 968-triangle smooth-normal blob, flattened; the config says 10M) + sky HDRI, {w}x{h}"
+    else:
+        w, h = args.width or 1920, args.height or 1080
+        sc = scenes.torture(args.tris, w, h, seed=12345)
+        ext = abi.FLAG_POINT_LIGHTS | abi.FLAG_MIS
+        if args.no_lights:
+            ext = 0
+        what = (f"C5: {args.tris}-triangle soup, 64 textured materials, " +
+                ("256 point lights + MIS (build-defined extensions, parity unpinned)" if ext else "reference behaviour (lights ignored, no MIS)") + f", {w}x{h}")
+    return sc, ext, what
 
 
 def main():
@@ -86,18 +154,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C2", help="BASELINE.json scene (default C2, the one the metric is quoted on)")
     ap.add_argument("--tris", type=int, default=1_000_000)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--max-bounces", type=int, default=8)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--max-bounces", type=int, default=0, help="0 -> the config's own")
+    ap.add_argument("--no-lights", action="store_true", help="C5 without the point-light / MIS extensions (reference behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=18.0)
+    ap.add_argument("--cpu-budget", type=float, default=16.0)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's all-core leg (0 = every core this job may use)")
+    ap.add_argument("--no-trace-phase", action="store_true", help="skip the single-pool pass that measures the traversal phase alone")
     ap.add_argument("--per-step-launch", action="store_true", help="one launch per step instead of one launch for all K steps")
     ap.add_argument("--schedule", choices=["auto", "wavefront", "fused", "megakernel"], default="auto")
     ap.add_argument("--gpu-build", action="store_true", help="build the BVH on the GPU (ER_FLAG_GPU_BUILD) instead of the host SAH build")
     ap.add_argument("--sim-world", type=int, default=0, help="(diagnostic) render only rank --sim-rank's tiles of this many, no collective")
     ap.add_argument("--sim-rank", type=int, default=0)
     args = ap.parse_args()
+    max_bounces = args.max_bounces or CONFIGS[args.config][1]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -126,14 +199,18 @@ def main():
     else:
         torch.cuda.set_device(local_rank)
 
-    scene = scenes.soup(args.tris, args.width, args.height, seed=12345)
+    scene, ext_flags, workload = make_scene(args, scenes, abi)
     shard_rank, shard_world = (args.sim_rank, args.sim_world) if (args.sim_world > 1 and world == 1) else (rank, world)
     sched_flag = {"auto": 0, "wavefront": abi.FLAG_WAVEFRONT, "fused": abi.FLAG_FUSED, "megakernel": abi.FLAG_MEGAKERNEL}[args.schedule]
-    pars = render.RenderParameters(sampleTarget=256, max_bounces=args.max_bounces, device=f"hip:{local_rank}",
-                                   rank=shard_rank, world=shard_world,
-                                   flags=abi.FLAG_PROFILE | sched_flag | (abi.FLAG_GPU_BUILD if args.gpu_build else 0))
-    rm = render.RenderingManager(pars)
-    rm.start_rendering(scene)
+    base_flags = sched_flag | ext_flags | (abi.FLAG_GPU_BUILD if args.gpu_build else 0)
+
+    def manager(extra_flags):
+        rm_ = render.RenderingManager(render.RenderParameters(sampleTarget=CONFIGS[args.config][2], max_bounces=max_bounces, device=f"hip:{local_rank}",
+                                                              rank=shard_rank, world=shard_world, flags=base_flags | extra_flags))
+        rm_.start_rendering(scene)
+        return rm_
+
+    rm = manager(abi.FLAG_PROFILE)
     accel = rm.accel_info()
 
     def sync_all():
@@ -153,7 +230,7 @@ def main():
     else:
         rm.render(args.steps, blocking=False)
     kernel_ms = rm.wait()
-    prof = rm.profile()      # per-kernel device time of the timed region (HIP events on the library's stream)
+    prof = rm.profile()      # per-kernel device time of the timed region (HIP events on the streams the launches ran on)
     sync_all()
     elapsed = time.perf_counter() - t0
     c_after = rm.counters()
@@ -172,17 +249,18 @@ def main():
 
     # ---- framebuffer combine (once per read-back, outside the timed region) ----
     t_rb = time.perf_counter()
+    gather_path = None
     if dist is not None:
         from elevenrender_amd import dist as erdist
-        rows = [rm.owned_count(r) for r in range(world)]
-        mine = torch.zeros((rows[rank], 4), dtype=torch.float32, device="cuda")
-        rm.pack_owned(abi.PASS_BEAUTY, mine.data_ptr())
-
-        def unpack(r, t):
-            t = t.contiguous().cuda()
-            torch.cuda.synchronize()
-            rm.unpack_owned(abi.PASS_BEAUTY, r, t.data_ptr())
-        erdist.gather_plane(dist, rank, world, mine.to(coll_dev), max(rows), unpack)
+        if rehearsal:
+            erdist.gather_all_planes_torch(dist, rm, rank, world)     # gloo on the host: the test harness path
+            gather_path = "torch.distributed (gloo rehearsal)"
+        else:
+            comm = erdist.NativeComm(dist, rank, world, local_rank)   # RCCL communicator made by the library's C++ side
+            for p in range(abi.PASS_COUNT):
+                comm.gather_pass(rm, p)                               # er_gather_pass: pack -> ncclSend/ncclRecv -> unpack
+            comm.close()
+            gather_path = "er_gather_pass (RCCL from the C++ side, 5 planes)"
         torch.cuda.synchronize()
     beauty_mean = None
     if rank == 0:
@@ -193,11 +271,8 @@ def main():
 
     result = None
     if rank == 0:
-        # ---- roofline: algorithmic bytes per launch from an instrumented replay of the same samples ----
-        inst = render.RenderingManager(render.RenderParameters(sampleTarget=256, max_bounces=args.max_bounces,
-                                                               device=f"hip:{local_rank}", rank=shard_rank, world=shard_world,
-                                                               flags=abi.FLAG_COUNTERS | sched_flag | (abi.FLAG_GPU_BUILD if args.gpu_build else 0)))
-        inst.start_rendering(scene)
+        # ---- roofline: algorithmic bytes from an instrumented replay of the same samples ----
+        inst = manager(abi.FLAG_COUNTERS)
         n_inst = min(2, args.steps)
         inst.render(n_inst)
         ci = inst.counters()
@@ -214,17 +289,49 @@ def main():
         sched = {abi.FLAG_WAVEFRONT: "wavefront", abi.FLAG_FUSED: "fused", abi.FLAG_MEGAKERNEL: "megakernel"}.get(prof["schedule"], "?")
         kernel_name = {"wavefront": "er_wf_trace", "fused": "er_fused_kernel", "megakernel": "er_render_kernel"}.get(sched, "?")
         if sched != "wavefront":
+            layout_b = path_b + (layout_b - trace_b)
             trace_b = path_b      # the single kernel of these schedules does the whole path
-            layout_b = path_b + (layout_b - trace_bytes(ci) / max(1, ci["rays"]) * my_rays)
-        # the wavefront schedule runs `conc` slot pools side by side, each on its own stream: launches overlap, so
-        # the rate the kernel sustains is conc x (bytes of one launch / duration of one launch).  Conservative: a
-        # trace launch also shares the chip with the other pools' shade launches for part of its duration.
-        conc = max(1, int(prof.get("concurrency", 1)))
+        wall_s = max(kernel_ms * 1e-3, 1e-9)        # device time of the whole timed region (HIP events on the library's stream)
+        achieved = trace_b / wall_s / 1e9           # ALL traversal bytes of the region / its wall time -- no concurrency factor
         per_launch = (trace_b / t_launches) / (trace_ms_avg * 1e-3) / 1e9 if trace_ms_avg > 0 else 0.0
-        achieved = per_launch * conc
+
+        # ---- trace phase alone: the same steps with ONE slot pool on ONE stream (launch durations are then exclusive) ----
+        trace_phase = None
+        if sched == "wavefront" and not args.no_trace_phase:
+            os.environ["ER_WF_POOLS"] = "1"
+            try:
+                one = manager(abi.FLAG_PROFILE | (0 if sched_flag else abi.FLAG_WAVEFRONT))
+            finally:
+                del os.environ["ER_WF_POOLS"]
+            if args.warmup > 0:
+                one.render(args.warmup)
+            c0 = one.counters()
+            torch.cuda.synchronize()
+            one.render(args.steps, blocking=False)
+            one_ms = one.wait()
+            p1 = one.profile()
+            c1 = one.counters()
+            one.close()
+            rays1 = c1["rays"] - c0["rays"]
+            b1 = trace_bytes(ci) / max(1, ci["rays"]) * rays1
+            tp = b1 / max(p1["trace_ms"] * 1e-3, 1e-9) / 1e9
+            trace_phase = {"schedule": "wavefront, 1 slot pool, 1 stream (launches do not overlap: bytes / summed trace-launch time is exact)",
+                           "achieved": round(tp, 2), "frac": round(tp / HBM_PEAK_GBS, 4),
+                           "trace_ms_total": round(p1["trace_ms"], 3), "shade_ms_total": round(p1["shade_ms"], 3), "region_ms": round(one_ms, 3),
+                           "trace_launches": p1["trace_launches"], "empty_launches": p1["empty_launches"],
+                           "Msamples_per_s": round((c1["bounce_samples"] - c0["bounce_samples"]) / max(one_ms * 1e-3, 1e-9) / 1e6, 2)}
+
+        # ---- measured HBM peak, same job ----
+        try:
+            copy_gbs, read_gbs = render.measure_hbm_peak(local_rank)
+        except Exception as e:     # measurement helper only; the line stays valid without it
+            copy_gbs, read_gbs = None, None
+            print(f"er_measure_hbm_peak failed: {e}", file=sys.stderr)
+        peak_measured = max(copy_gbs or 0.0, read_gbs or 0.0) or None
+
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes
-        if os.path.exists(tf) and world == 1 and args.tris == 1_000_000:
+        tf = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes
+        if os.path.exists(tf) and world == 1 and args.config == "C2" and args.tris == 1_000_000:
             try:
                 traffic = json.load(open(tf)).get("er_wf_trace_hbm_bytes_per_launch")
             except Exception:
@@ -235,29 +342,40 @@ def main():
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2: {args.tris}-triangle random soup + 2048x1024 sky HDRI, {args.width}x{args.height}, "
-                                   f"max_bounces {args.max_bounces}, 1 step = 1 spp pass (config total 256 spp), seed 12345",
+            "config": {"workload": f"{workload}, max_bounces {max_bounces}, 1 step = 1 spp pass (config total {CONFIGS[args.config][2]} spp), seed 12345",
                        "sharding": f"8x8 pixel tiles, (tx+ty) % {shard_world}", "calls_in_timed_region": launches,
                        "schedule": sched},
             "paths_per_s": round(paths / elapsed, 1), "rays_per_s": round(rays / elapsed, 1),
             "mean_path_length": round(samples / max(1, paths), 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": kernel_name, "launches": prof["trace_launches"], "concurrent_launches": conc,
+                         "kernel": kernel_name,
+                         "definition": "achieved = all traversal bytes of the timed region (64 B/node visit + 36 B/triangle test, SURVEY 8d) / device time of the region",
+                         "peak_measured": round(peak_measured, 1) if peak_measured else None,
+                         "peak_measured_copy": round(copy_gbs, 1) if copy_gbs else None, "peak_measured_read": round(read_gbs, 1) if read_gbs else None,
+                         "frac_of_measured": round(achieved / peak_measured, 4) if peak_measured else None,
+                         "trace_phase": trace_phase,
+                         "launches": prof["trace_launches"], "empty_launches": prof["empty_launches"], "empty_ms": round(prof["empty_ms"], 3),
+                         "pools_side_by_side": max(1, int(prof.get("concurrency", 1))),
                          "achieved_per_launch": round(per_launch, 2),
-                         "achieved_own_layout": round(per_launch * conc * layout_b / max(trace_b, 1.0), 2),
+                         "achieved_own_layout": round(achieved * layout_b / max(trace_b, 1.0), 2),
                          "avg_launch_ms": round(trace_ms_avg, 5), "algorithmic_bytes_per_launch": round(trace_b / t_launches, 1),
                          "trace_ms_total": round(prof["trace_ms"], 3), "shade_ms_total": round(prof["shade_ms"], 3),
-                         "whole_path_GBps": round(path_b / (kernel_ms * 1e-3) / 1e9, 2) if kernel_ms > 0 else None,
+                         "region_ms": round(kernel_ms, 3),
+                         "whole_path_GBps": round(path_b / wall_s / 1e9, 2),
                          "node_visits_per_ray": round(ci["node_visits"] / max(1, ci["rays"]), 2),
                          "tri_tests_per_ray": round(ci["tri_tests"] / max(1, ci["rays"]), 2)},
             "accel": {"nodes": accel["node_count"], "node_bytes": accel["node_bytes"], "leaves": accel["leaf_count"],
                       "max_depth": accel["max_depth"], "build_ms": round(accel["build_ms"], 1), "builder": "device linear BVH" if accel["builder"] else "host binned SAH", "upload_ms": round(accel["upload_ms"], 2)},
-            "readback_ms": round(readback_ms, 2), "beauty_mean": beauty_mean,
+            "readback_ms": round(readback_ms, 2), "gather": gather_path, "beauty_mean": beauty_mean,
         }
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(scene, args.max_bounces, args.cpu_budget)
-            result["gpu_over_cpu"] = round(value / max(result["cpu_baseline"]["value"], 1e-12), 1)
+            if args.config == "C4":
+                result["cpu_baseline"] = None     # the reference's host BVH build alone takes minutes at 9.68M triangles
+            else:
+                threads = args.cpu_threads or host_cores()
+                result["cpu_baseline"] = cpu_baseline(scene, max_bounces, ext_flags, threads, args.cpu_budget)
+                result["gpu_over_cpu"] = round(value / max(result["cpu_baseline"]["value"], 1e-12), 1)
     rm.close()
     if dist is not None:
         dist.barrier()

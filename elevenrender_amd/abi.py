@@ -11,13 +11,14 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeleven_hip.so")
+# ELEVEN_HIP_LIB: load another build of the same library (tools/sanitize_cpu.sh points it at the ASan + UBSan build)
+LIB_PATH = os.environ.get("ELEVEN_HIP_LIB") or os.path.join(_HERE, "libeleven_hip.so")
 
 ER_OK = 0
 ER_ERR_INVALID_ARG, ER_ERR_NO_DEVICE, ER_ERR_HIP, ER_ERR_STATE, ER_ERR_OOM = -1, -2, -3, -4, -5
 PASS_BEAUTY, PASS_DENOISE, PASS_NORMAL, PASS_TANGENT, PASS_BITANGENT, PASS_COUNT = 0, 1, 2, 3, 4, 5
 PASS_NAMES = {"beauty": 0, "denoise": 1, "normal": 2, "tangent": 3, "bitangent": 4}
-FLAG_POINT_LIGHTS, FLAG_COUNTERS, FLAG_MEGAKERNEL, FLAG_PROFILE, FLAG_FUSED, FLAG_WAVEFRONT, FLAG_GPU_BUILD = 1, 2, 4, 8, 16, 32, 64
+FLAG_POINT_LIGHTS, FLAG_COUNTERS, FLAG_MEGAKERNEL, FLAG_PROFILE, FLAG_FUSED, FLAG_WAVEFRONT, FLAG_GPU_BUILD, FLAG_MIS = 1, 2, 4, 8, 16, 32, 64, 128
 
 
 class ErVec3(C.Structure):
@@ -84,7 +85,7 @@ class ErCounters(C.Structure):
 
 class ErProfile(C.Structure):
     _fields_ = [("trace_ms", C.c_float), ("shade_ms", C.c_float), ("trace_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("schedule", C.c_uint32),
-                ("concurrency", C.c_uint32)]
+                ("concurrency", C.c_uint32), ("empty_launches", C.c_uint32), ("empty_ms", C.c_float), ("rays_logged", C.c_uint64)]
 
 
 class ErAccelInfo(C.Structure):
@@ -93,8 +94,15 @@ class ErAccelInfo(C.Structure):
                 ("upload_ms", C.c_float), ("lift_bound", C.c_float), ("builder", C.c_uint32)]
 
 
+class ErTraceRec(C.Structure):   # include/eleven_hip_debug.h; same layout as the oracle's OracleTraceRec
+    _fields_ = [("bounce", C.c_int32), ("tri", C.c_int32), ("shadow_tri", C.c_int32), ("opaque", C.c_int32),
+                ("position", C.c_float * 3), ("wi", C.c_float * 3), ("light", C.c_float * 3), ("reduction", C.c_float * 3),
+                ("shadow_occ", C.c_int32), ("light_occ", C.c_int32)]
+
+
 # every symbol include/eleven_hip.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
+_FP, _IP = C.POINTER(C.c_float), C.POINTER(C.c_int32)
 SYMBOLS = {
     "er_abi_version": (C.c_int, []),
     "er_last_error": (C.c_char_p, []),
@@ -118,6 +126,15 @@ SYMBOLS = {
     "er_accel_info": (C.c_int, [_P, C.POINTER(ErAccelInfo)]),
     "er_get_profile": (C.c_int, [_P, C.POINTER(ErProfile)]),
     "er_denoise": (C.c_int, [_P, C.c_uint32, C.c_float]),
+    "er_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "er_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P)]),
+    "er_comm_destroy": (None, [_P]),
+    "er_gather_pass": (C.c_int, [_P, C.c_int, _P, C.c_uint32]),
+    "er_debug_comm_create_local": (C.c_int, [C.c_uint32, C.POINTER(_P)]),
+    "er_measure_hbm_peak": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, _FP, _FP]),
+    "er_debug_trace_rays": (C.c_int, [_P, _FP, _FP, C.c_uint32, _IP, _FP, _IP, _IP, _FP, _FP, _IP]),
+    "er_debug_trace_pixel": (C.c_int, [_P, C.c_uint32, C.POINTER(ErTraceRec), C.c_int, C.POINTER(C.c_int)]),
+    "er_debug_set_host_alloc_limit": (None, [C.c_uint64]),
     "er_debug_closest_hit": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_float),
                                        C.POINTER(C.c_float)]),
 }

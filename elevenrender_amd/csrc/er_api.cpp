@@ -3,212 +3,11 @@
 // copy_scene, renderSetup, kernel_render_enqueue and RenderingManager::get_pass
 // (reference src/kernel.cpp:244-266,651-706; src/SYCLCopy.cpp:3-104; src/Managers.cpp:287-302).
 // There is NO CPU fallback: without a usable HIP device every compute entry point fails.
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "../../include/eleven_hip.h"
 #include <chrono>
-#include "er_bvh.h"
-#include "er_gpu_build.h"
-#include "er_device.h"
-#include "er_kernels.h"
-#include "er_wavefront.h"
 
-namespace {
+#include "er_scene.h"
 
-thread_local std::string g_err;
-
-int fail(int code, const std::string& msg) {
-    g_err = msg;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                                   \
-    do {                                                                                                \
-        hipError_t e__ = (expr);                                                                        \
-        if (e__ != hipSuccess)                                                                          \
-            return fail(e__ == hipErrorOutOfMemory ? ER_ERR_OOM : ER_ERR_HIP,                           \
-                        std::string(#expr) + ": " + hipGetErrorString(e__));                            \
-    } while (0)
-
-struct HostTex {
-    int32_t width, height, channels, filter;
-    std::vector<float> data;
-};
-
-// Texture::getValueFromCoordinates, reference src/Texture.cpp:172-200 (host copy, used by the CDF)
-void host_tex_coords(const HostTex& t, int x, int y, float out[3]) {
-    x %= t.width;
-    y %= t.height;
-    if (x < 0) x *= -1;
-    if (y < 0) y *= -1;
-    out[0] = out[1] = out[2] = 0.0f;
-    const float* d = t.data.data();
-    if (t.channels == 1) {
-        out[0] = out[1] = out[2] = d[y * t.width + x];
-    } else if (t.channels == 2) {
-        out[0] = d[t.channels * (y * t.width + x) + 0];
-        out[1] = d[t.channels * (y * t.width + x) + 1];
-    } else if (t.channels >= 3) {
-        out[0] = d[t.channels * (y * t.width + x) + 0];
-        out[1] = d[t.channels * (y * t.width + x) + 1];
-        out[2] = d[t.channels * (y * t.width + x) + 2];
-    }
-}
-
-// HDRI::generateCDF, reference src/HDRI.cpp:62-83 (host preparation, same float sequence)
-void host_generate_cdf(const HostTex& t, std::vector<float>& cdf, float& radianceSum) {
-    int c = 0;
-    radianceSum = 0;
-    cdf.assign((size_t)t.width * t.height + 1, 0.0f);
-    float p[3];
-    for (int j = 0; j < t.height; j++)
-        for (int i = 0; i < t.width; i++) {
-            host_tex_coords(t, i, j, p);
-            radianceSum += p[0] + p[1] + p[2];
-        }
-    for (int j = 0; j < t.height; j++)
-        for (int i = 0; i < t.width; i++) {
-            host_tex_coords(t, i, j, p);
-            cdf[c + 1] = cdf[c] + (p[0] + p[1] + p[2]) / radianceSum;
-            c++;
-        }
-}
-
-template <class T>
-struct DevBuf {
-    T* p = nullptr;
-    size_t n = 0;
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        n = 0;
-    }
-};
-
-}  // namespace
-
-struct ErScene {
-    // host copy of the description
-    uint32_t tri_count = 0;
-    std::vector<float> vertices, normals, tangents, uvs, tangent_sign;
-    std::vector<int32_t> material_id;
-    std::vector<ErMaterial> materials;
-    std::vector<HostTex> textures;
-    HostTex hdri_tex;
-    std::vector<float> hdri_cdf;
-    float hdri_radiance_sum = 0;
-    ErCamera camera;
-    std::vector<ErPointLight> point_lights;
-    uint32_t x_res = 0, y_res = 0;
-
-    // render state
-    bool begun = false;
-    int device = 0;
-    ErRenderParams params{};
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool timing_open = false;
-    DevScene dev{};
-    ErAccelInfo accel{};
-    DevBuf<float4> d_nodes, d_nodes8, d_isect, d_attr, d_passes;
-    DevBuf<ErMaterial> d_materials;
-    DevBuf<DevTex> d_textures;
-    DevBuf<float> d_tex_pool, d_cdf;
-    DevBuf<uint32_t> d_samples, d_rng, d_owned;
-    DevBuf<DevCounters> d_counters;
-    DevBuf<float4> d_wf4;        // 11 float4 arrays of the wavefront state, back to back
-    DevBuf<uint32_t> d_wf1;      // hit, left, occluded, 4 queues, counts
-    DevBuf<uint2> d_spill;
-    DevBuf<uint32_t> d_guide, d_ticket;
-    uint32_t fused_blocks = 0;
-    std::vector<WfState> wf;              // slot pools (see er_render_begin)
-    std::vector<hipStream_t> pool_streams;   // pool 0 runs on `stream`, pool p > 0 on pool_streams[p - 1]
-    std::vector<hipEvent_t> pool_events;     // [0] fork; [p] pool p has finished
-
-    uint32_t trace_blocks = 0, shade_blocks = 0;
-    std::vector<hipEvent_t> prof_events;   // ER_FLAG_PROFILE: e[3i], e[3i+1], e[3i+2] = before trace, between, after shade
-    size_t prof_used = 0;
-    ErProfile profile{};
-    std::map<uint32_t, DevBuf<uint32_t>> d_rank_tiles;   // tile lists of other ranks (for unpack)
-    std::mutex mtx;
-
-    std::vector<uint32_t> tiles_of(uint32_t rank, uint32_t world) const {
-        std::vector<uint32_t> t;
-        uint32_t tiles_x = (x_res + ER_TILE - 1) / ER_TILE, tiles_y = (y_res + ER_TILE - 1) / ER_TILE;
-        for (uint32_t ty = 0; ty < tiles_y; ty++)
-            for (uint32_t tx = 0; tx < tiles_x; tx++)
-                if ((tx + ty) % world == rank) t.push_back(ty * tiles_x + tx);
-        return t;
-    }
-    void release_device() {
-        d_nodes.release(); d_nodes8.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_materials.release();
-        d_textures.release(); d_tex_pool.release(); d_cdf.release(); d_samples.release(); d_rng.release();
-        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release();
-        for (auto& kv : d_rank_tiles) kv.second.release();
-        d_rank_tiles.clear();
-        for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
-        prof_events.clear();
-        prof_used = 0;
-        for (hipEvent_t e : pool_events) (void)hipEventDestroy(e);
-        pool_events.clear();
-        for (hipStream_t st : pool_streams) (void)hipStreamDestroy(st);
-        pool_streams.clear();
-        wf.clear();
-        if (ev_start) (void)hipEventDestroy(ev_start);
-        if (ev_stop) (void)hipEventDestroy(ev_stop);
-        if (stream) (void)hipStreamDestroy(stream);
-        ev_start = ev_stop = nullptr;
-        stream = nullptr;
-        begun = false;
-        timing_open = false;
-    }
-};
-
-namespace {
-
-// guide table of er_cdf.h: guide[j] = first i in [0,length] with cdf[i] >= j/buckets
-int er_build_cdf_guide(const float* cdf, int length, std::vector<uint32_t>& guide) {
-    int buckets = 1;
-    while (buckets < length / 8 && buckets < (1 << 22)) buckets <<= 1;
-    guide.assign((size_t)buckets + 1, (uint32_t)length);
-    int i = 0;
-    for (int j = 0; j <= buckets; j++) {
-        float thr = (float)j / (float)buckets;
-        while (i < length && cdf[i] < thr) i++;
-        guide[j] = (uint32_t)i;
-    }
-    return buckets;
-}
-
-template <class T>
-int upload(DevBuf<T>& b, const void* src, size_t count, hipStream_t s) {
-    b.release();
-    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
-    HIP_TRY(hipMalloc((void**)&b.p, bytes));
-    b.n = count;
-    if (count && src) HIP_TRY(hipMemcpyAsync(b.p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
-    return ER_OK;
-}
-
-int copy_tex(const ErTexture& in, HostTex& out, const char* what) {
-    if (in.width <= 0 || in.height <= 0 || in.channels < 0 || (in.channels > 0 && !in.data))
-        return fail(ER_ERR_INVALID_ARG, std::string("bad texture: ") + what);
-    out.width = in.width; out.height = in.height; out.channels = in.channels; out.filter = in.filter;
-    size_t n = (size_t)in.width * in.height * in.channels;
-    out.data.assign(in.data, in.data + n);
-    return ER_OK;
-}
-
-}  // namespace
+using namespace erh;
 
 extern "C" {
 
@@ -221,7 +20,7 @@ int er_device_count(void) {
     return n;
 }
 
-int er_device_info(int index, ErDeviceInfo* out) {
+static int er_device_info_impl(int index, ErDeviceInfo* out) {
     if (!out) return fail(ER_ERR_INVALID_ARG, "er_device_info: out is NULL");
     int n = er_device_count();
     if (index < 0 || index >= n) return fail(ER_ERR_NO_DEVICE, "er_device_info: no such HIP device");
@@ -237,7 +36,7 @@ int er_device_info(int index, ErDeviceInfo* out) {
     return ER_OK;
 }
 
-int er_device_find(const char* selector) {
+static int er_device_find_impl(const char* selector) {
     if (!selector) return fail(ER_ERR_INVALID_ARG, "er_device_find: selector is NULL");
     int n = er_device_count();
     for (int i = 0; i < n; i++) {
@@ -249,7 +48,7 @@ int er_device_find(const char* selector) {
     return fail(ER_ERR_NO_DEVICE, std::string("er_device_find: no device matches '") + selector + "'");
 }
 
-int er_scene_create(const ErSceneDesc* d, ErScene** out) {
+static int er_scene_create_impl(const ErSceneDesc* d, ErScene** out) {
     if (!d || !out) return fail(ER_ERR_INVALID_ARG, "er_scene_create: NULL argument");
     *out = nullptr;
     if (d->x_res == 0 || d->y_res == 0) return fail(ER_ERR_INVALID_ARG, "er_scene_create: zero resolution");
@@ -258,9 +57,17 @@ int er_scene_create(const ErSceneDesc* d, ErScene** out) {
     if (d->tri_count && (!d->vertices || !d->normals || !d->tangents || !d->uvs || !d->tangent_sign || !d->material_id))
         return fail(ER_ERR_INVALID_ARG, "er_scene_create: triangle arrays missing");
     if (d->material_count == 0 || !d->materials) return fail(ER_ERR_INVALID_ARG, "er_scene_create: at least one material is required");
-    ErScene* s = new (std::nothrow) ErScene();
-    if (!s) return fail(ER_ERR_OOM, "er_scene_create: out of host memory");
     size_t n = d->tri_count;
+    {   // what the host copy of the description will take (texel payloads + 31 floats per triangle + the HDRI CDF)
+        uint64_t bytes = (uint64_t)n * (9 * 3 + 6 + 1 + 1) * 4 + (uint64_t)d->material_count * sizeof(ErMaterial);
+        for (uint32_t i = 0; i < d->texture_count && d->textures; i++)
+            bytes += (uint64_t)std::max(0, d->textures[i].width) * std::max(0, d->textures[i].height) * std::max(0, d->textures[i].channels) * 4;
+        bytes += (uint64_t)std::max(0, d->hdri.texture.width) * std::max(0, d->hdri.texture.height) * (std::max(0, d->hdri.texture.channels) + 1) * 4;
+        host_reserve(bytes);
+    }
+    if (d->texture_count && !d->textures) return fail(ER_ERR_INVALID_ARG, "er_scene_create: texture table missing");
+    std::unique_ptr<ErScene> owner(new ErScene());   // released to the caller only on success
+    ErScene* s = owner.get();
     s->tri_count = d->tri_count;
     if (n) {
         s->vertices.assign(d->vertices, d->vertices + n * 9);
@@ -272,7 +79,6 @@ int er_scene_create(const ErSceneDesc* d, ErScene** out) {
     }
     for (size_t i = 0; i < n; i++)
         if (s->material_id[i] < 0 || (uint32_t)s->material_id[i] >= d->material_count) {
-            delete s;
             return fail(ER_ERR_INVALID_ARG, "er_scene_create: material_id out of range");
         }
     s->materials.assign(d->materials, d->materials + d->material_count);
@@ -280,17 +86,16 @@ int er_scene_create(const ErSceneDesc* d, ErScene** out) {
         const int32_t ids[7] = {m.albedo_tex, m.emission_tex, m.roughness_tex, m.metallic_tex, m.normal_tex, m.opacity_tex, m.transmission_tex};
         for (int32_t id : ids)
             if (id >= (int32_t)d->texture_count) {
-                delete s;
                 return fail(ER_ERR_INVALID_ARG, "er_scene_create: texture id out of range");
             }
     }
     s->textures.resize(d->texture_count);
     for (uint32_t i = 0; i < d->texture_count; i++) {
         int rc = copy_tex(d->textures[i], s->textures[i], "scene texture");
-        if (rc != ER_OK) { delete s; return rc; }
+        if (rc != ER_OK) return rc;
     }
     int rc = copy_tex(d->hdri.texture, s->hdri_tex, "hdri");
-    if (rc != ER_OK) { delete s; return rc; }
+    if (rc != ER_OK) return rc;
     if (d->hdri.cdf) {
         s->hdri_cdf.assign(d->hdri.cdf, d->hdri.cdf + (size_t)s->hdri_tex.width * s->hdri_tex.height + 1);
         s->hdri_radiance_sum = d->hdri.radiance_sum;
@@ -301,7 +106,7 @@ int er_scene_create(const ErSceneDesc* d, ErScene** out) {
     if (d->point_light_count && d->point_lights) s->point_lights.assign(d->point_lights, d->point_lights + d->point_light_count);
     s->x_res = d->x_res;
     s->y_res = d->y_res;
-    *out = s;
+    *out = owner.release();
     return ER_OK;
 }
 
@@ -315,12 +120,11 @@ void er_scene_destroy(ErScene* s) {
     delete s;
 }
 
-int er_render_begin(ErScene* s, const ErRenderParams* p) {
+static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     if (!s || !p) return fail(ER_ERR_INVALID_ARG, "er_render_begin: NULL argument");
     std::lock_guard<std::mutex> lk(s->mtx);
     uint32_t world = p->world ? p->world : 1;
     if (p->rank >= world) return fail(ER_ERR_INVALID_ARG, "er_render_begin: rank >= world");
-    if (p->flags & ER_FLAG_POINT_LIGHTS) return fail(ER_ERR_INVALID_ARG, "er_render_begin: ER_FLAG_POINT_LIGHTS is not implemented yet");
     int ndev = er_device_count();
     if (ndev <= 0) return fail(ER_ERR_NO_DEVICE, "er_render_begin: no HIP device available (there is no CPU fallback)");
     if (p->device < 0 || p->device >= ndev) return fail(ER_ERR_NO_DEVICE, "er_render_begin: device ordinal out of range");
@@ -353,9 +157,28 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     double build_ms = 0;
     bool built = false;
     int rc;
-    hipEvent_t u0, u1;
-    HIP_TRY(hipEventCreate(&u0));
-    HIP_TRY(hipEventCreate(&u1));
+    EventPair ev;                       // destroyed on every return path
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+    const hipEvent_t u0 = ev.a, u1 = ev.b;
+    // Staging buffers of the asynchronous uploads below.  They live until the stream has been synchronised at the
+    // end of this function (HIP happens to make pageable host-to-device copies host-synchronous; this code does
+    // not rely on it).
+    ErBvhBuild bvh;
+    std::vector<ErTriIsect> isect;
+    std::vector<ErTriAttr> attr;
+    std::vector<float4> geom;
+    // Probe one kernel of every translation unit before the first launch: a library that carries no code object
+    // this device can run (a stale or mis-targeted build) makes hipLaunchKernelGGL dereference a null function
+    // inside the runtime (recorded in round 1: SIGSEGV under er_launch_setup after "No compatible code objects
+    // found for gfx950:sramecc+:xnack-").  hipFuncGetAttributes reports the same condition as an error code.
+    {
+        const char* which = nullptr;
+        hipError_t pe = er_probe_kernels(&which);
+        if (pe != hipSuccess)
+            return fail(ER_ERR_HIP, std::string("er_render_begin: libeleven_hip.so has no usable gfx950 code object for ") + (which ? which : "?") +
+                                        " on this device (" + hipGetErrorString(pe) + "); rebuild with `make -C elevenrender_amd/csrc`");
+    }
     if (((p->flags & ER_FLAG_GPU_BUILD) || getenv("ER_GPU_BUILD")) && s->tri_count > ER_BVH_LEAF_MAX) {
         // whole structure on the device (er_gpu_build.hip): tree, wide-node collapse, slot order, triangle records
         std::string why;
@@ -364,11 +187,12 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
         int brc = er_gpu_build_device(arrays, s->tri_count, s->device, &g, why);
         if (brc < 0) return fail(ER_ERR_HIP, "er_render_begin: device BVH build: " + why);
         if (brc == 0) {
-            if (g.geom_f4 >= (1ull << 30)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: geometry exceeds the 16 GB addressable by the wide traversal");
+            // the scene owns the three buffers from here on (release_device frees them on any later error)
             s->d_nodes.release(); s->d_nodes8.release(); s->d_attr.release();
             s->d_nodes.p = g.nodes; s->d_nodes.n = g.nodes_f4;
             s->d_nodes8.p = g.geom; s->d_nodes8.n = g.geom_f4;
             s->d_attr.p = g.attr; s->d_attr.n = g.attr_f4;
+            if (g.geom_f4 >= (1ull << 30)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: geometry exceeds the 16 GB addressable by the wide traversal");
             n8_pieces = g.n8_pieces;
             bvh2_nodes = (uint32_t)(g.nodes_f4 / 4); wide_nodes = g.nodes8_count; wide_depth = g.max_depth8; leaf_count = g.leaf_count;
             for (int a = 0; a < 3; a++) { bvh_lo[a] = g.lo[a]; bvh_hi[a] = g.hi[a]; }
@@ -379,13 +203,13 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     }
     if (built) HIP_TRY(hipEventRecord(u0, s->stream));
     if (!built) {
-        ErBvhBuild bvh;
+        host_reserve((uint64_t)n * (sizeof(ErTriIsect) * 2 + sizeof(ErTriAttr) + 2 * sizeof(ErNode)));
         er_build_bvh(s->vertices.data(), s->normals.data(), s->tri_count, 0, &bvh);
         HIP_TRY(hipEventRecord(u0, s->stream));
         if (bvh.max_depth > ER_BVH_MAX_DEPTH) return fail(ER_ERR_STATE, "er_render_begin: BVH deeper than the traversal stack");
         if (bvh.max_depth8 > ER_BVH_MAX_DEPTH) return fail(ER_ERR_STATE, "er_render_begin: wide BVH deeper than the traversal stack");
-        std::vector<ErTriIsect> isect(n + 1);      // +1: the wide traversal fetches triangles in pairs
-        std::vector<ErTriAttr> attr(n);
+        isect.resize(n + 1);      // +1: the wide traversal fetches triangles in pairs
+        attr.resize(n);
         for (size_t slot = 0; slot < n; slot++) {
             uint32_t id = bvh.slot_to_tri[slot];
             const float* v = &s->vertices[(size_t)id * 9];
@@ -406,7 +230,7 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
         // wide nodes and triangle records share ONE buffer: the wide traversal addresses both with a 32-bit
         // offset in 16-byte units
         n8_pieces = bvh.nodes8.size() * 5 + 3;   // + padding: a step fetches 96 B from a node's start
-        std::vector<float4> geom(n8_pieces + (n + 1) * 3, make_float4(0, 0, 0, 0));
+        geom.assign(n8_pieces + (n + 1) * 3, make_float4(0, 0, 0, 0));
         if (!bvh.nodes8.empty()) memcpy(geom.data(), bvh.nodes8.data(), bvh.nodes8.size() * sizeof(ErNode8));
         memcpy(geom.data() + n8_pieces, isect.data(), (n + 1) * sizeof(ErTriIsect));
         if (geom.size() >= (1ull << 30)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: geometry exceeds the 16 GB addressable by the wide traversal");
@@ -418,6 +242,9 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
         build_ms = bvh.build_ms;
     }
     if ((rc = upload(s->d_materials, s->materials.data(), s->materials.size(), s->stream)) != ER_OK) return rc;
+    if ((rc = upload(s->d_lights, s->point_lights.data(), s->point_lights.size(), s->stream)) != ER_OK) return rc;
+    // point-light queries double the shadow records and the shadow queues of the wavefront schedule (er_wavefront.h)
+    const bool lights_on = (p->flags & ER_FLAG_POINT_LIGHTS) != 0 && !s->point_lights.empty();
 
     // textures: one float pool + a table
     std::vector<DevTex> table(s->textures.size());
@@ -476,19 +303,23 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
         const size_t pool_tiles = (owned.size() + pools - 1) / pools;
         const size_t qcap = pool_tiles * 64;          // queue capacity of one pool
         size_t slots = owned.size() * 64;
-        if ((rc = upload(s->d_wf4, nullptr, slots * 11, s->stream)) != ER_OK) return rc;
-        if ((rc = upload(s->d_wf1, nullptr, slots * 6 + qcap * pools * 4 + (size_t)WF_COUNTS * pools, s->stream)) != ER_OK) return rc;
+        const size_t sh = lights_on ? 2 : 1;          // shadow records per slot: [slot] HDRI query, [slot + slots] point light
+        const size_t qs_cap = qcap * sh;              // shadow-queue capacity of one pool
+        const size_t q_words = 2 * qcap + 2 * qs_cap; // two closest + two shadow queues per pool
+        if ((rc = upload(s->d_wf4, nullptr, slots * (7 + 4 * sh), s->stream)) != ER_OK) return rc;
+        if ((rc = upload(s->d_wf1, nullptr, slots * (3 + 3 * sh) + q_words * pools + (size_t)WF_COUNTS * pools, s->stream)) != ER_OK) return rc;
         WfState W{};
         float4* f = s->d_wf4.p;
         W.ray_o = f; W.ray_d = f + slots; W.light = f + 2 * slots; W.reduc = f + 3 * slots;
         W.aov_n = f + 4 * slots; W.aov_t = f + 5 * slots; W.aov_b = f + 6 * slots;
-        W.sh_o = f + 7 * slots; W.sh_d = f + 8 * slots; W.c_vis = f + 9 * slots; W.c_occ = f + 10 * slots;
+        W.sh_o = f + 7 * slots; W.sh_d = W.sh_o + sh * slots; W.c_vis = W.sh_d + sh * slots; W.c_occ = W.c_vis + sh * slots;
         uint32_t* u = s->d_wf1.p;
-        W.hit = (int*)u; W.left = u + slots; W.occluded = (int*)(u + 2 * slots);
-        W.hit2 = (int*)(u + 3 * slots); W.occ_a = (int*)(u + 4 * slots); W.occ_b = (int*)(u + 5 * slots);
-        uint32_t* qbase = u + 6 * slots;
-        uint32_t* cbase = qbase + qcap * pools * 4;
+        W.hit = (int*)u; W.left = u + slots; W.hit2 = (int*)(u + 2 * slots);
+        W.occluded = (int*)(u + 3 * slots); W.occ_a = W.occluded + sh * slots; W.occ_b = W.occ_a + sh * slots;
+        uint32_t* qbase = u + (3 + 3 * sh) * slots;
+        uint32_t* cbase = qbase + q_words * pools;
         W.pools = pools;
+        W.slots = (uint32_t)slots;
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         uint32_t cus = (uint32_t)prop.multiProcessorCount;
@@ -503,8 +334,8 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
         s->wf.clear();
         for (uint32_t p2 = 0; p2 < pools; p2++) {
             W.pool = p2;
-            uint32_t* q = qbase + (size_t)p2 * qcap * 4;
-            W.q[0] = q; W.q[1] = q + qcap; W.qs[0] = q + 2 * qcap; W.qs[1] = q + 3 * qcap;
+            uint32_t* q = qbase + (size_t)p2 * q_words;
+            W.q[0] = q; W.q[1] = q + qcap; W.qs[0] = q + 2 * qcap; W.qs[1] = q + 2 * qcap + qs_cap;
             W.counts = cbase + (size_t)p2 * WF_COUNTS;
             W.spill = s->d_spill.p + (size_t)p2 * spill_per_pool;
             s->wf.push_back(W);
@@ -552,6 +383,9 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     D.tiles_x = (s->x_res + ER_TILE - 1) / ER_TILE;
     D.tiles_y = (s->y_res + ER_TILE - 1) / ER_TILE;
     D.max_bounces = s->params.max_bounces;
+    D.ext_flags = s->params.flags & (ER_FLAG_POINT_LIGHTS | ER_FLAG_MIS);
+    D.lights = s->d_lights.p;
+    D.light_count = (uint32_t)s->point_lights.size();
     D.passes = s->d_passes.p;
     D.samples = s->d_samples.p;
     D.rng = s->d_rng.p;
@@ -564,8 +398,6 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     float up_ms = 0;
     (void)hipEventElapsedTime(&up_ms, u0, u1);
-    (void)hipEventDestroy(u0);
-    (void)hipEventDestroy(u1);
 
     s->accel.node_count = wide_nodes;
     s->accel.node_bytes = sizeof(ErNode8);
@@ -580,7 +412,7 @@ int er_render_begin(ErScene* s, const ErRenderParams* p) {
     return ER_OK;
 }
 
-int er_render_samples_async(ErScene* s, uint32_t n) {
+static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_render_samples: NULL scene");
     std::lock_guard<std::mutex> lk(s->mtx);
     if (!s->begun) return fail(ER_ERR_STATE, "er_render_samples: er_render_begin has not succeeded");
@@ -614,10 +446,23 @@ int er_render_samples_async(ErScene* s, uint32_t n) {
         const uint32_t pools = (uint32_t)s->wf.size();
         const bool prof = (s->params.flags & ER_FLAG_PROFILE) != 0;
         if (prof) {
-            while (s->prof_events.size() < s->prof_used + 3 * (size_t)iters * pools) {
+            const size_t need = s->prof_used / 3 + (size_t)iters * pools;      // launches profiled since the last er_wait
+            while (s->prof_events.size() < 3 * need) {
                 hipEvent_t e;
                 HIP_TRY(hipEventCreate(&e));
                 s->prof_events.push_back(e);
+            }
+            if (s->d_ray_log.n < need) {
+                // grow, keeping what earlier calls of this timing window logged (they are still in flight or done)
+                DevBuf<uint32_t> bigger;
+                int rc2 = upload(bigger, nullptr, need * 2, s->stream);
+                if (rc2 != ER_OK) return rc2;
+                if (s->d_ray_log.p && s->prof_used) {
+                    HIP_TRY(hipStreamSynchronize(s->stream));
+                    HIP_TRY(hipMemcpy(bigger.p, s->d_ray_log.p, (s->prof_used / 3) * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+                }
+                s->d_ray_log.release();
+                s->d_ray_log = bigger;
             }
         }
         // fork: the pool streams start after everything already enqueued on the scene's stream
@@ -630,8 +475,9 @@ int er_render_samples_async(ErScene* s, uint32_t n) {
         for (uint32_t it = 0; it < iters; it++) {
             for (uint32_t p = 0; p < pools; p++) {
                 hipStream_t st = pool_stream(p);
+                uint32_t* ray_log = prof ? s->d_ray_log.p + s->prof_used / 3 : nullptr;
                 if (prof) HIP_TRY(hipEventRecord(s->prof_events[s->prof_used++], st));
-                er_launch_wf_trace(s->dev, s->wf[p], it & 1, count, s->trace_blocks, st);
+                er_launch_wf_trace(s->dev, s->wf[p], it & 1, count, s->trace_blocks, ray_log, st);
                 if (prof) HIP_TRY(hipEventRecord(s->prof_events[s->prof_used++], st));
                 er_launch_wf_shade(s->dev, s->wf[p], it & 1, count, s->shade_blocks, st);
                 if (prof) HIP_TRY(hipEventRecord(s->prof_events[s->prof_used++], st));
@@ -647,7 +493,7 @@ int er_render_samples_async(ErScene* s, uint32_t n) {
     return ER_OK;
 }
 
-int er_wait(ErScene* s, float* elapsed_ms) {
+static int er_wait_impl(ErScene* s, float* elapsed_ms) {
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_wait: NULL scene");
     std::lock_guard<std::mutex> lk(s->mtx);
     if (!s->begun) return fail(ER_ERR_STATE, "er_wait: er_render_begin has not succeeded");
@@ -665,20 +511,35 @@ int er_wait(ErScene* s, float* elapsed_ms) {
     s->profile = ErProfile{};
     s->profile.schedule = s->params.flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT);
     s->profile.concurrency = (s->params.flags & ER_FLAG_WAVEFRONT) ? (uint32_t)std::max<size_t>(1, s->wf.size()) : 1u;
+    // The wavefront host loop always enqueues n * (max_bounces + 1) iterations per pool; the last ones find empty
+    // queues (a path rarely takes every bounce).  Those launches are reported apart, so that per-launch figures are
+    // averages over launches that traced something.
+    std::vector<uint32_t> ray_log;
+    const bool wf = (s->params.flags & ER_FLAG_WAVEFRONT) != 0;
+    if (wf && s->prof_used && s->d_ray_log.p) {
+        ray_log.resize(s->prof_used / 3);
+        HIP_TRY(hipMemcpy(ray_log.data(), s->d_ray_log.p, ray_log.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
     for (size_t i = 0; i + 2 < s->prof_used; i += 3) {
         float a = 0, b = 0;
         HIP_TRY(hipEventElapsedTime(&a, s->prof_events[i], s->prof_events[i + 1]));
         HIP_TRY(hipEventElapsedTime(&b, s->prof_events[i + 1], s->prof_events[i + 2]));
+        if (wf && i / 3 < ray_log.size() && ray_log[i / 3] == 0) {
+            s->profile.empty_launches++;
+            s->profile.empty_ms += a + b;
+            continue;
+        }
         s->profile.trace_ms += a;
         s->profile.shade_ms += b;
         s->profile.trace_launches++;
         s->profile.shade_launches++;
+        if (wf && i / 3 < ray_log.size()) s->profile.rays_logged += ray_log[i / 3];
     }
     s->prof_used = 0;
     return ER_OK;
 }
 
-int er_render_samples(ErScene* s, uint32_t n) {
+static int er_render_samples_impl(ErScene* s, uint32_t n) {
     int rc = er_render_samples_async(s, n);
     if (rc != ER_OK) return rc;
     return er_wait(s, nullptr);
@@ -695,11 +556,12 @@ static int read_back(ErScene* s, const void* src, void* dst, size_t bytes, const
     return ER_OK;
 }
 
-int er_samples_done(ErScene* s, uint32_t* out) {
+static int er_samples_done_impl(ErScene* s, uint32_t* out) {
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_samples_done: NULL scene");
     // dev_samples[0], reference src/Managers.cpp:217-221; with tile sharding pixel 0 may belong to another
     // rank, so report the first owned pixel instead.
     uint32_t first = 0;
+    std::unique_lock<std::mutex> lk(s->mtx);
     if (s->begun && s->params.world > 1) {
         std::vector<uint32_t> t = s->tiles_of(s->params.rank, s->params.world);
         if (!t.empty()) {
@@ -707,16 +569,17 @@ int er_samples_done(ErScene* s, uint32_t* out) {
             first = (t[0] / tiles_x) * ER_TILE * s->x_res + (t[0] % tiles_x) * ER_TILE;
         }
     }
+    lk.unlock();
     return read_back(s, s->d_samples.p + first, out, sizeof(uint32_t), "er_samples_done");
 }
 
-int er_read_pass(ErScene* s, int pass, float* dst) {
+static int er_read_pass_impl(ErScene* s, int pass, float* dst) {
     if (pass < 0 || pass >= ER_PASS_COUNT) return fail(ER_ERR_INVALID_ARG, "er_read_pass: pass out of range");
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_read_pass: NULL scene");
     size_t npx = (size_t)s->x_res * s->y_res;
     return read_back(s, s->d_passes.p + (size_t)pass * npx, dst, npx * sizeof(float4), "er_read_pass");
 }
-int er_denoise(ErScene* s, uint32_t levels, float colour_sigma) {
+static int er_denoise_impl(ErScene* s, uint32_t levels, float colour_sigma) {
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_denoise: NULL scene");
     std::lock_guard<std::mutex> lk(s->mtx);
     if (!s->begun) return fail(ER_ERR_STATE, "er_denoise: er_render_begin has not succeeded");
@@ -727,7 +590,7 @@ int er_denoise(ErScene* s, uint32_t levels, float colour_sigma) {
     if (colour_sigma == 0) colour_sigma = 1.0f;
     HIP_TRY(hipSetDevice(s->device));
     const size_t npx = (size_t)s->x_res * s->y_res;
-    DevBuf<float4> tmp;
+    ScopedDevBuf<float4> tmp;
     int rc;
     if ((rc = upload(tmp, (const void*)nullptr, npx, s->stream)) != ER_OK) return rc;
     const float4* beauty = s->d_passes.p + (size_t)ER_PASS_BEAUTY * npx;
@@ -744,20 +607,19 @@ int er_denoise(ErScene* s, uint32_t levels, float colour_sigma) {
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
-    tmp.release();
     return ER_OK;
 }
 
-int er_read_samples(ErScene* s, uint32_t* dst) {
+static int er_read_samples_impl(ErScene* s, uint32_t* dst) {
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_read_samples: NULL scene");
     return read_back(s, s->d_samples.p, dst, (size_t)s->x_res * s->y_res * 4, "er_read_samples");
 }
-int er_read_rng(ErScene* s, uint32_t* dst) {
+static int er_read_rng_impl(ErScene* s, uint32_t* dst) {
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_read_rng: NULL scene");
     return read_back(s, s->d_rng.p, dst, (size_t)s->x_res * s->y_res * 4, "er_read_rng");
 }
 
-int er_owned_count(ErScene* s, uint32_t rank, uint64_t* out) {
+static int er_owned_count_impl(ErScene* s, uint32_t rank, uint64_t* out) {
     if (!s || !out) return fail(ER_ERR_INVALID_ARG, "er_owned_count: NULL argument");
     uint32_t world = s->begun ? s->params.world : 1;
     if (rank >= world) return fail(ER_ERR_INVALID_ARG, "er_owned_count: rank >= world");
@@ -765,7 +627,7 @@ int er_owned_count(ErScene* s, uint32_t rank, uint64_t* out) {
     return ER_OK;
 }
 
-int er_pack_owned(ErScene* s, int pass, void* dev_dst) {
+static int er_pack_owned_impl(ErScene* s, int pass, void* dev_dst) {
     if (!s || !dev_dst) return fail(ER_ERR_INVALID_ARG, "er_pack_owned: NULL argument");
     if (pass < 0 || pass >= ER_PASS_COUNT) return fail(ER_ERR_INVALID_ARG, "er_pack_owned: pass out of range");
     std::lock_guard<std::mutex> lk(s->mtx);
@@ -777,7 +639,7 @@ int er_pack_owned(ErScene* s, int pass, void* dev_dst) {
     return ER_OK;
 }
 
-int er_unpack_owned(ErScene* s, int pass, uint32_t src_rank, const void* dev_src) {
+static int er_unpack_owned_impl(ErScene* s, int pass, uint32_t src_rank, const void* dev_src) {
     if (!s || !dev_src) return fail(ER_ERR_INVALID_ARG, "er_unpack_owned: NULL argument");
     if (pass < 0 || pass >= ER_PASS_COUNT) return fail(ER_ERR_INVALID_ARG, "er_unpack_owned: pass out of range");
     std::lock_guard<std::mutex> lk(s->mtx);
@@ -787,11 +649,12 @@ int er_unpack_owned(ErScene* s, int pass, uint32_t src_rank, const void* dev_src
     auto it = s->d_rank_tiles.find(src_rank);
     if (it == s->d_rank_tiles.end()) {
         std::vector<uint32_t> t = s->tiles_of(src_rank, s->params.world);
-        DevBuf<uint32_t> b;
+        ScopedDevBuf<uint32_t> b;
         int rc = upload(b, t.data(), t.size(), s->stream);
         if (rc != ER_OK) return rc;
         HIP_TRY(hipStreamSynchronize(s->stream));   // t goes out of scope
-        it = s->d_rank_tiles.emplace(src_rank, b).first;
+        it = s->d_rank_tiles.emplace(src_rank, DevBuf<uint32_t>(b)).first;
+        b.p = nullptr;                               // now owned by the scene
     }
     er_launch_unpack(s->dev, it->second.p, (uint32_t)it->second.n, pass, dev_src, s->stream);
     HIP_TRY(hipGetLastError());
@@ -799,7 +662,7 @@ int er_unpack_owned(ErScene* s, int pass, uint32_t src_rank, const void* dev_src
     return ER_OK;
 }
 
-int er_get_counters(ErScene* s, ErCounters* out) {
+static int er_get_counters_impl(ErScene* s, ErCounters* out) {
     if (!s || !out) return fail(ER_ERR_INVALID_ARG, "er_get_counters: NULL argument");
     DevCounters c;
     int rc = read_back(s, s->d_counters.p, &c, sizeof(c), "er_get_counters");
@@ -810,14 +673,14 @@ int er_get_counters(ErScene* s, ErCounters* out) {
     return ER_OK;
 }
 
-int er_get_profile(ErScene* s, ErProfile* out) {
+static int er_get_profile_impl(ErScene* s, ErProfile* out) {
     if (!s || !out) return fail(ER_ERR_INVALID_ARG, "er_get_profile: NULL argument");
     if (!s->begun) return fail(ER_ERR_STATE, "er_get_profile: er_render_begin has not succeeded");
     *out = s->profile;
     return ER_OK;
 }
 
-int er_accel_info(ErScene* s, ErAccelInfo* out) {
+static int er_accel_info_impl(ErScene* s, ErAccelInfo* out) {
     if (!s || !out) return fail(ER_ERR_INVALID_ARG, "er_accel_info: NULL argument");
     if (!s->begun) return fail(ER_ERR_STATE, "er_accel_info: er_render_begin has not succeeded");
     *out = s->accel;
@@ -826,111 +689,24 @@ int er_accel_info(ErScene* s, ErAccelInfo* out) {
 
 }  // extern "C"
 
-// ---- host-only debug hook (include/eleven_hip_debug.h) ----
-#include "../../include/eleven_hip_debug.h"
-
-extern "C" int er_debug_closest_hit(ErScene* s, const float* origins, const float* dirs, uint32_t n, int32_t* tri_ids, float* positions, float* distances) {
-    if (!s || !origins || !dirs || !tri_ids || !positions || !distances) return fail(ER_ERR_INVALID_ARG, "er_debug_closest_hit: NULL argument");
-    std::lock_guard<std::mutex> lk(s->mtx);
-    if (!s->begun) return fail(ER_ERR_STATE, "er_debug_closest_hit: er_render_begin has not succeeded");
-    HIP_TRY(hipSetDevice(s->device));
-    DevBuf<float> d_o, d_d, d_pos, d_dist;
-    DevBuf<int32_t> d_tri;
-    int rc;
-    if ((rc = upload(d_o, origins, (size_t)n * 3, s->stream)) != ER_OK) return rc;
-    if ((rc = upload(d_d, dirs, (size_t)n * 3, s->stream)) != ER_OK) return rc;
-    if ((rc = upload(d_pos, (const float*)nullptr, (size_t)n * 3, s->stream)) != ER_OK) return rc;
-    if ((rc = upload(d_dist, (const float*)nullptr, (size_t)n, s->stream)) != ER_OK) return rc;
-    if ((rc = upload(d_tri, (const int32_t*)nullptr, (size_t)n, s->stream)) != ER_OK) return rc;
-    er_launch_debug_hit(s->dev, d_o.p, d_d.p, n, d_tri.p, d_pos.p, d_dist.p, s->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(tri_ids, d_tri.p, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(positions, d_pos.p, (size_t)n * 12, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipMemcpyAsync(distances, d_dist.p, (size_t)n * 4, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    d_o.release(); d_d.release(); d_pos.release(); d_dist.release(); d_tri.release();
-    return ER_OK;
-}
-
-extern "C" int er_debug_cdf_search(const float* cdf, int length, const float* values, int32_t* out, int count) {
-    if (!cdf || !values || !out || length <= 0) return fail(ER_ERR_INVALID_ARG, "er_debug_cdf_search: bad argument");
-    std::vector<uint32_t> guide;
-    int buckets = er_build_cdf_guide(cdf, length, guide);
-    for (int i = 0; i < count; i++) out[i] = er_cdf_search(cdf, length, guide.data(), buckets, values[i]);
-    return ER_OK;
-}
-
-extern "C" int er_debug_bvh_check(const float* vertices, const float* normals, uint32_t tri_count, int threads, ErBvhCheck* out) {
-    if (!out || (tri_count && (!vertices || !normals))) return fail(ER_ERR_INVALID_ARG, "er_debug_bvh_check: NULL argument");
-    ErBvhBuild b;
-    er_build_bvh(vertices, normals, tri_count, threads, &b);
-    memset(out, 0, sizeof(*out));
-    out->node_count = (uint32_t)b.nodes.size();
-    out->leaf_count = b.leaf_count;
-    out->max_depth = b.max_depth;
-    out->lift_bound = b.lift_bound;
-    out->build_ms = (float)b.build_ms;
-    std::vector<uint8_t> seen(tri_count, 0), visited(b.nodes.size(), 0);
-    struct Item { int32_t ref; float lo[3], hi[3]; bool has_box; };
-    std::vector<Item> stack;
-    if (!b.nodes.empty()) stack.push_back(Item{0, {0, 0, 0}, {0, 0, 0}, false});
-    auto area = [](const float* lo, const float* hi) {
-        float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
-        return 2.0 * ((double)x * y + (double)x * z + (double)y * z);
-    };
-    double root_area = 0;
-    if (!b.nodes.empty()) {
-        const ErNode& r = b.nodes[0];
-        float lo[3], hi[3];
-        for (int a = 0; a < 3; a++) {
-            lo[a] = r.c1 == ER_BVH_NO_CHILD ? r.lo0[a] : std::min(r.lo0[a], r.lo1[a]);
-            hi[a] = r.c1 == ER_BVH_NO_CHILD ? r.hi0[a] : std::max(r.hi0[a], r.hi1[a]);
-        }
-        root_area = area(lo, hi);
-    }
-    while (!stack.empty()) {
-        Item it = stack.back();
-        stack.pop_back();
-        if (it.ref == ER_BVH_NO_CHILD) continue;
-        if (it.ref >= 0) {
-            if ((size_t)it.ref >= b.nodes.size()) { out->uncontained++; continue; }
-            if (visited[it.ref]++) { out->duplicate_tris++; continue; }
-            const ErNode& n = b.nodes[it.ref];
-            const float* los[2] = {n.lo0, n.lo1};
-            const float* his[2] = {n.hi0, n.hi1};
-            const int32_t cs[2] = {n.c0, n.c1};
-            for (int k = 0; k < 2; k++) {
-                if (cs[k] == ER_BVH_NO_CHILD) continue;
-                if (it.has_box)
-                    for (int a = 0; a < 3; a++)
-                        if (los[k][a] < it.lo[a] || his[k][a] > it.hi[a]) out->uncontained++;
-                Item c;
-                c.ref = cs[k];
-                c.has_box = true;
-                memcpy(c.lo, los[k], 12);
-                memcpy(c.hi, his[k], 12);
-                uint32_t cnt = 0;
-                if (cs[k] < 0) cnt = ((uint32_t)~cs[k] & 7u) + 1;
-                if (root_area > 0) out->sah_cost += area(los[k], his[k]) / root_area * (cs[k] < 0 ? cnt : 1.0);
-                stack.push_back(c);
-            }
-        } else {
-            uint32_t v = (uint32_t)~it.ref, first = v >> 3, cnt = (v & 7u) + 1;
-            out->max_leaf_size = std::max(out->max_leaf_size, cnt);
-            for (uint32_t i = 0; i < cnt; i++) {
-                uint32_t slot = first + i;
-                if (slot >= tri_count) { out->uncontained++; continue; }
-                uint32_t id = b.slot_to_tri[slot];
-                if (seen[id]++) out->duplicate_tris++;
-                out->tris_in_leaves++;
-                for (int k = 0; k < 3; k++)
-                    for (int a = 0; a < 3; a++) {
-                        float p = vertices[(size_t)id * 9 + k * 3 + a];
-                        if (p < it.lo[a] || p > it.hi[a]) out->uncontained++;
-                    }
-            }
-        }
-    }
-    for (uint8_t v : visited) if (!v) out->unreachable_nodes++;
-    return ER_OK;
-}
+// ---- the exported entry points: every body above runs inside guarded() (no exception crosses the C ABI) ----
+extern "C" {
+int er_device_info(int index, ErDeviceInfo* out) { return guarded("er_device_info", [&]() -> int { return er_device_info_impl(index, out); }); }
+int er_device_find(const char* selector) { return guarded("er_device_find", [&]() -> int { return er_device_find_impl(selector); }); }
+int er_scene_create(const ErSceneDesc* d, ErScene** out) { return guarded("er_scene_create", [&]() -> int { return er_scene_create_impl(d, out); }); }
+int er_render_begin(ErScene* s, const ErRenderParams* p) { return guarded("er_render_begin", [&]() -> int { return er_render_begin_impl(s, p); }); }
+int er_render_samples_async(ErScene* s, uint32_t n) { return guarded("er_render_samples_async", [&]() -> int { return er_render_samples_async_impl(s, n); }); }
+int er_wait(ErScene* s, float* elapsed_ms) { return guarded("er_wait", [&]() -> int { return er_wait_impl(s, elapsed_ms); }); }
+int er_render_samples(ErScene* s, uint32_t n) { return guarded("er_render_samples", [&]() -> int { return er_render_samples_impl(s, n); }); }
+int er_samples_done(ErScene* s, uint32_t* out) { return guarded("er_samples_done", [&]() -> int { return er_samples_done_impl(s, out); }); }
+int er_read_pass(ErScene* s, int pass, float* dst) { return guarded("er_read_pass", [&]() -> int { return er_read_pass_impl(s, pass, dst); }); }
+int er_denoise(ErScene* s, uint32_t levels, float colour_sigma) { return guarded("er_denoise", [&]() -> int { return er_denoise_impl(s, levels, colour_sigma); }); }
+int er_read_samples(ErScene* s, uint32_t* dst) { return guarded("er_read_samples", [&]() -> int { return er_read_samples_impl(s, dst); }); }
+int er_read_rng(ErScene* s, uint32_t* dst) { return guarded("er_read_rng", [&]() -> int { return er_read_rng_impl(s, dst); }); }
+int er_owned_count(ErScene* s, uint32_t rank, uint64_t* out) { return guarded("er_owned_count", [&]() -> int { return er_owned_count_impl(s, rank, out); }); }
+int er_pack_owned(ErScene* s, int pass, void* dev_dst) { return guarded("er_pack_owned", [&]() -> int { return er_pack_owned_impl(s, pass, dev_dst); }); }
+int er_unpack_owned(ErScene* s, int pass, uint32_t src_rank, const void* dev_src) { return guarded("er_unpack_owned", [&]() -> int { return er_unpack_owned_impl(s, pass, src_rank, dev_src); }); }
+int er_get_counters(ErScene* s, ErCounters* out) { return guarded("er_get_counters", [&]() -> int { return er_get_counters_impl(s, out); }); }
+int er_get_profile(ErScene* s, ErProfile* out) { return guarded("er_get_profile", [&]() -> int { return er_get_profile_impl(s, out); }); }
+int er_accel_info(ErScene* s, ErAccelInfo* out) { return guarded("er_accel_info", [&]() -> int { return er_accel_info_impl(s, out); }); }
+}  // extern "C"

@@ -1,0 +1,258 @@
+// er_collective.cpp -- er_comm_* / er_gather_pass of include/eleven_hip.h: see er_collective.h.
+#include "er_collective.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: every call goes through the table below (dlopen, no link dependency)
+
+#include "er_scene.h"
+
+using namespace erh;
+
+namespace {
+
+// ---- RCCL, resolved at run time ----
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {getenv("ER_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+            r.error = dlerror();
+        }
+        if (!r.lib) return;
+        bool ok = true;
+        auto sym = [&](const char* name) {
+            void* p = dlsym(r.lib, name);
+            if (!p) { ok = false; r.error = std::string("missing symbol ") + name; }
+            return p;
+        };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        if (!ok) { dlclose(r.lib); r.lib = nullptr; }
+    });
+    return r;
+}
+
+int nccl_fail(const char* what, ncclResult_t e) {
+    Rccl& r = rccl();
+    return fail(ER_ERR_HIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(e) : "RCCL error"));
+}
+
+struct RcclSelf { ncclComm_t comm = nullptr; };
+
+int rccl_group_start(void*) { ncclResult_t e = rccl().GroupStart(); return e == ncclSuccess ? ER_OK : nccl_fail("ncclGroupStart", e); }
+int rccl_group_end(void*) { ncclResult_t e = rccl().GroupEnd(); return e == ncclSuccess ? ER_OK : nccl_fail("ncclGroupEnd", e); }
+int rccl_send(void* self, const void* buf, size_t bytes, uint32_t peer, hipStream_t st) {
+    ncclResult_t e = rccl().Send(buf, bytes, ncclUint8, (int)peer, ((RcclSelf*)self)->comm, st);
+    return e == ncclSuccess ? ER_OK : nccl_fail("ncclSend", e);
+}
+int rccl_recv(void* self, void* buf, size_t bytes, uint32_t peer, hipStream_t st) {
+    ncclResult_t e = rccl().Recv(buf, bytes, ncclUint8, (int)peer, ((RcclSelf*)self)->comm, st);
+    return e == ncclSuccess ? ER_OK : nccl_fail("ncclRecv", e);
+}
+void rccl_destroy(void* self) {
+    RcclSelf* s = (RcclSelf*)self;
+    if (s->comm) (void)rccl().CommDestroy(s->comm);
+    delete s;
+}
+
+// ---- loopback transport: `world` ranks in one process on one GPU (tests).  A send parks a device copy of the buffer
+// in the shared mailbox; the matching recv (which must come later: the calls of one process are sequential) takes it. ----
+struct Mailbox {
+    std::mutex mtx;
+    std::map<std::pair<uint32_t, uint32_t>, std::pair<void*, size_t>> slots;   // (src, dst) -> device copy
+    uint64_t bytes_moved = 0, messages = 0;
+    ~Mailbox() {
+        for (auto& kv : slots) (void)hipFree(kv.second.first);
+    }
+};
+struct LocalSelf {
+    std::shared_ptr<Mailbox> box;
+    uint32_t rank;
+};
+int local_nop(void*) { return ER_OK; }
+int local_send(void* self, const void* buf, size_t bytes, uint32_t peer, hipStream_t st) {
+    LocalSelf* s = (LocalSelf*)self;
+    void* copy = nullptr;
+    HIP_TRY(hipMalloc(&copy, std::max<size_t>(bytes, 1)));
+    hipError_t e = hipMemcpyAsync(copy, buf, bytes, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { (void)hipFree(copy); return fail(ER_ERR_HIP, std::string("loopback send: ") + hipGetErrorString(e)); }
+    std::lock_guard<std::mutex> lk(s->box->mtx);
+    auto key = std::make_pair(s->rank, peer);
+    auto it = s->box->slots.find(key);
+    if (it != s->box->slots.end()) { (void)hipFree(it->second.first); s->box->slots.erase(it); }
+    s->box->slots[key] = std::make_pair(copy, bytes);
+    s->box->bytes_moved += bytes;
+    s->box->messages++;
+    return ER_OK;
+}
+int local_recv(void* self, void* buf, size_t bytes, uint32_t peer, hipStream_t st) {
+    LocalSelf* s = (LocalSelf*)self;
+    std::pair<void*, size_t> msg;
+    {
+        std::lock_guard<std::mutex> lk(s->box->mtx);
+        auto it = s->box->slots.find(std::make_pair(peer, s->rank));
+        if (it == s->box->slots.end()) return fail(ER_ERR_STATE, "loopback recv: rank " + std::to_string(peer) + " has not sent yet (call the non-root ranks first)");
+        msg = it->second;
+        s->box->slots.erase(it);
+    }
+    int rc = ER_OK;
+    if (msg.second != bytes) rc = fail(ER_ERR_STATE, "loopback recv: size mismatch (" + std::to_string(msg.second) + " sent, " + std::to_string(bytes) + " expected)");
+    if (rc == ER_OK) {
+        hipError_t e = hipMemcpyAsync(buf, msg.first, bytes, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(ER_ERR_HIP, std::string("loopback recv: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(msg.first);
+    return rc;
+}
+void local_destroy(void* self) { delete (LocalSelf*)self; }
+
+}  // namespace
+
+static int er_comm_unique_id_impl(uint8_t* id) {
+    if (!id) return fail(ER_ERR_INVALID_ARG, "er_comm_unique_id: NULL argument");
+    Rccl& r = rccl();
+    if (!r.lib) return fail(ER_ERR_NO_DEVICE, "er_comm_unique_id: RCCL is not loadable (" + r.error + ")");
+    static_assert(sizeof(ncclUniqueId) == ER_COMM_ID_BYTES, "ER_COMM_ID_BYTES must be RCCL's NCCL_UNIQUE_ID_BYTES");
+    ncclUniqueId u;
+    ncclResult_t e = r.GetUniqueId(&u);
+    if (e != ncclSuccess) return nccl_fail("ncclGetUniqueId", e);
+    memcpy(id, &u, sizeof(u));
+    return ER_OK;
+}
+
+static int er_comm_create_impl(const uint8_t* id, uint32_t rank, uint32_t world, int device, ErComm** out) {
+    if (!id || !out) return fail(ER_ERR_INVALID_ARG, "er_comm_create: NULL argument");
+    *out = nullptr;
+    if (world == 0 || rank >= world) return fail(ER_ERR_INVALID_ARG, "er_comm_create: rank >= world");
+    Rccl& r = rccl();
+    if (!r.lib) return fail(ER_ERR_NO_DEVICE, "er_comm_create: RCCL is not loadable (" + r.error + ")");
+    if (device < 0 || device >= er_device_count()) return fail(ER_ERR_NO_DEVICE, "er_comm_create: device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<RcclSelf> self(new RcclSelf());
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    ncclResult_t e = r.CommInitRank(&self->comm, (int)world, u, (int)rank);
+    if (e != ncclSuccess) return nccl_fail("ncclCommInitRank", e);
+    ErComm* c = new ErComm();
+    c->t = ErTransport{rccl_group_start, rccl_group_end, rccl_send, rccl_recv, rccl_destroy, "rccl"};
+    c->self = self.release();
+    c->rank = rank; c->world = world; c->device = device;
+    *out = c;
+    return ER_OK;
+}
+
+static int er_debug_comm_create_local_impl(uint32_t world, ErComm** out) {
+    if (!out || world == 0) return fail(ER_ERR_INVALID_ARG, "er_debug_comm_create_local: bad argument");
+    auto box = std::make_shared<Mailbox>();
+    for (uint32_t r = 0; r < world; r++) {
+        ErComm* c = new ErComm();
+        c->t = ErTransport{local_nop, local_nop, local_send, local_recv, local_destroy, "loopback"};
+        c->self = new LocalSelf{box, r};
+        c->rank = r; c->world = world; c->device = -1;
+        out[r] = c;
+    }
+    return ER_OK;
+}
+
+// pack -> exchange -> unpack of ONE plane (ER_PASS_COUNT = the sample-count plane).  Every rank of the communicator
+// calls it with its own scene; after it the root's full plane holds every rank's pixels.
+static int er_gather_pass_impl(ErScene* s, int pass, ErComm* c, uint32_t root) {
+    if (!s || !c) return fail(ER_ERR_INVALID_ARG, "er_gather_pass: NULL argument");
+    if (pass < 0 || pass >= ER_PASS_COUNT) return fail(ER_ERR_INVALID_ARG, "er_gather_pass: pass out of range");
+    if (root >= c->world) return fail(ER_ERR_INVALID_ARG, "er_gather_pass: root >= world");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if (!s->begun) return fail(ER_ERR_STATE, "er_gather_pass: er_render_begin has not succeeded");
+    if (s->params.world != c->world || s->params.rank != c->rank)
+        return fail(ER_ERR_INVALID_ARG, "er_gather_pass: the scene's rank/world differ from the communicator's");
+    if (c->world == 1) return ER_OK;     // the plane is already whole
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = s->stream;          // ordered after every sample enqueued so far
+    int rc;
+    if (c->rank != root) {
+        const size_t n = (size_t)s->dev.owned_tile_count * 64;
+        ScopedDevBuf<float4> mine;
+        if ((rc = upload(mine, (const float4*)nullptr, n, st)) != ER_OK) return rc;
+        er_launch_pack(s->dev, s->d_owned.p, s->dev.owned_tile_count, pass, mine.p, st);
+        HIP_TRY(hipGetLastError());
+        if ((rc = c->t.group_start(c->self)) != ER_OK) return rc;
+        rc = c->t.send(c->self, mine.p, n * sizeof(float4), root, st);
+        int rc2 = c->t.group_end(c->self);
+        if (rc != ER_OK) return rc;
+        if (rc2 != ER_OK) return rc2;
+        HIP_TRY(hipStreamSynchronize(st));   // `mine` is freed on return
+        return ER_OK;
+    }
+    // root: one receive buffer per peer, all receives in ONE group (seven xGMI links side by side), then the scatters
+    std::vector<ScopedDevBuf<float4>> in(c->world);
+    std::vector<size_t> counts(c->world, 0);
+    for (uint32_t r = 0; r < c->world; r++) {
+        if (r == root) continue;
+        counts[r] = s->tiles_of(r, c->world).size() * 64;
+        if ((rc = upload(in[r], (const float4*)nullptr, counts[r], st)) != ER_OK) return rc;
+    }
+    if ((rc = c->t.group_start(c->self)) != ER_OK) return rc;
+    for (uint32_t r = 0; r < c->world && rc == ER_OK; r++)
+        if (r != root) rc = c->t.recv(c->self, in[r].p, counts[r] * sizeof(float4), r, st);
+    int rc2 = c->t.group_end(c->self);
+    if (rc != ER_OK) return rc;
+    if (rc2 != ER_OK) return rc2;
+    for (uint32_t r = 0; r < c->world; r++) {
+        if (r == root) continue;
+        auto it = s->d_rank_tiles.find(r);
+        if (it == s->d_rank_tiles.end()) {
+            std::vector<uint32_t> t = s->tiles_of(r, c->world);
+            ScopedDevBuf<uint32_t> b;
+            if ((rc = upload(b, t.data(), t.size(), st)) != ER_OK) return rc;
+            HIP_TRY(hipStreamSynchronize(st));   // t goes out of scope
+            it = s->d_rank_tiles.emplace(r, DevBuf<uint32_t>(b)).first;
+            b.p = nullptr;
+        }
+        er_launch_unpack(s->dev, it->second.p, (uint32_t)it->second.n, pass, in[r].p, st);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    return ER_OK;
+}
+
+extern "C" {
+int er_comm_unique_id(uint8_t* id) { return guarded("er_comm_unique_id", [&]() -> int { return er_comm_unique_id_impl(id); }); }
+int er_comm_create(const uint8_t* id, uint32_t rank, uint32_t world, int device, ErComm** out) {
+    return guarded("er_comm_create", [&]() -> int { return er_comm_create_impl(id, rank, world, device, out); });
+}
+void er_comm_destroy(ErComm* c) {
+    if (!c) return;
+    if (c->t.destroy) c->t.destroy(c->self);
+    delete c;
+}
+int er_gather_pass(ErScene* s, int pass, ErComm* c, uint32_t root) {
+    return guarded("er_gather_pass", [&]() -> int { return er_gather_pass_impl(s, pass, c, root); });
+}
+int er_debug_comm_create_local(uint32_t world, ErComm** out) {
+    return guarded("er_debug_comm_create_local", [&]() -> int { return er_debug_comm_create_local_impl(world, out); });
+}
+}  // extern "C"

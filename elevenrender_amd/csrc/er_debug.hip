@@ -1,0 +1,187 @@
+// er_debug.hip -- inspection and measurement kernels (include/eleven_hip_debug.h).  Not on the production path; they
+// run the production path's FUNCTIONS on inputs the tests choose, so that a mismatch against the oracle can be localised
+// to a ray or to a bounce (SURVEY.md section 4 levels 1-2; reference src/BVH.cpp:63-120, src/kernel.cpp:508-592).
+#include "er_debug.h"
+
+#include "er_device.h"
+#include "er_shade.h"
+#include "er_trav.h"
+
+using namespace erd;
+
+// ---- arbitrary rays through the production traversal ----
+__global__ __launch_bounds__(64) void er_debug_trace_kernel(DevScene S, const float* __restrict__ o, const float* __restrict__ d, uint32_t n,
+                                                             const int32_t* __restrict__ self, const float* __restrict__ limit,
+                                                             int32_t* __restrict__ tri_out, int32_t* __restrict__ slot_out, float* __restrict__ pos_out,
+                                                             float* __restrict__ dist_out, int32_t* __restrict__ info_out, uint2* spill_base) {
+    __shared__ uint2 s_stack[WF_LDS_STACK * 64];
+    __shared__ int s_stack2[ER_STACK * 64];
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    uint2* stack = s_stack + threadIdx.x;
+    uint2* spill = spill_base + (size_t)blockIdx.x * (ER_STACK * 64) + threadIdx.x;
+    int* stack2 = s_stack2 + threadIdx.x;
+    Ray ray;
+    ray.o = f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+    ray.d = f3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    unsigned cn = 0, ct = 0;
+    int info = 0;
+    if (self) {
+        const bool occ = trav_run_shadow<false>(S, stack, spill, stack2, ray, self[i], limit[i], info, cn, ct);
+        tri_out[i] = occ ? 1 : 0;
+        slot_out[i] = -1;
+        pos_out[3 * i] = pos_out[3 * i + 1] = pos_out[3 * i + 2] = 0.0f;
+        dist_out[i] = 0.0f;
+    } else {
+        const int slot = trav_run_closest<false>(S, stack, spill, stack2, ray, __builtin_inff(), info, cn, ct);
+        tri_out[i] = -1;
+        slot_out[i] = slot;
+        pos_out[3 * i] = pos_out[3 * i + 1] = pos_out[3 * i + 2] = 0.0f;
+        dist_out[i] = __builtin_inff();
+        if (slot >= 0) {
+            HitFull h;
+            full_hit(S, (uint32_t)slot, ray, h);
+            tri_out[i] = __builtin_bit_cast(int, S.tri_isect[(size_t)slot * 3].w);
+            pos_out[3 * i] = h.position.x; pos_out[3 * i + 1] = h.position.y; pos_out[3 * i + 2] = h.position.z;
+            dist_out[i] = length(h.position - ray.o);
+        }
+    }
+    info_out[i] = info;
+}
+
+void er_launch_debug_trace(const DevScene& S, const float* o, const float* d, uint32_t n, const int32_t* self, const float* limit, int32_t* tri,
+                           int32_t* slot, float* pos, float* dist, int32_t* info, void* spill, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(er_debug_trace_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, S, o, d, n, self, limit, tri, slot, pos, dist, info, (uint2*)spill);
+}
+
+// ---- per-bounce trace of one pixel-sample: bounce_step (er_shade.h) + the production traversal, queries traced at once ----
+namespace {
+
+struct PixelSink {
+    const DevScene& S;
+    uint2* stack;
+    uint2* spill;
+    int* stack2;
+    F3& light;
+    F3 &aov_n, &aov_t, &aov_b;
+    ErTraceRec* rec;
+    unsigned &c_rays, &c_nodes, &c_tris;
+    ERD int tri_id(int slot) const { return slot < 0 ? -1 : __builtin_bit_cast(int, S.tri_isect[(size_t)slot * 3].w); }
+    ERD void hdri_query(const Ray& sr, int self_slot, float d_self, F3 c_vis, F3 c_occ) {
+        int info;
+        c_rays++;
+        const bool occ = trav_run_shadow<false>(S, stack, spill, stack2, sr, self_slot, d_self, info, c_nodes, c_tris);
+        light = light + (occ ? c_occ : c_vis);
+        if (rec) {
+            rec->shadow_occ = occ ? 1 : 0;
+            // what the reference's throwRay(shadowRay) returns (src/kernel.cpp:556), for the record only
+            rec->shadow_tri = tri_id(trav_run_closest<false>(S, stack, spill, stack2, sr, __builtin_inff(), info, c_nodes, c_tris));
+        }
+    }
+    ERD void light_query(const Ray& lr, float limit, F3 l_vis, F3 l_occ) {
+        int info;
+        c_rays++;
+        const bool occ = trav_run_shadow<false>(S, stack, spill, stack2, lr, -1, limit, info, c_nodes, c_tris);
+        light = light + (occ ? l_occ : l_vis);
+        if (rec) rec->light_occ = occ ? 1 : 0;
+    }
+    ERD void first_hit(F3 n, F3 t, F3 b) { aov_n = n; aov_t = t; aov_b = b; }
+};
+
+}  // namespace
+
+template <bool EXT>
+__global__ __launch_bounds__(64) void er_debug_pixel_kernel(DevScene S, uint32_t idx, ErTraceRec* recs, int max_recs, int* count, uint2* spill) {
+    // (one lane, speed irrelevant: all three traversal stacks live in the HBM scratch buffer)
+    uint2* s_stack = spill + (size_t)ER_STACK * 64;
+    int* s_stack2 = (int*)(s_stack + (size_t)WF_LDS_STACK * 64);
+    if (threadIdx.x != 0) return;
+    int nrec = 0;
+    unsigned c_rays = 0, c_nodes = 0, c_tris = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;
+    uint32_t rs = S.rng[idx];
+    const uint32_t px = idx % S.x_res, py = idx / S.x_res;
+    float c1 = rng_next(rs), c2 = rng_next(rs), c3 = rng_next(rs), c4 = rng_next(rs), c5 = rng_next(rs);
+    Ray ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
+    F3 light = f3s(0), reduction = f3s(1), aov_n = f3s(0), aov_t = f3s(0), aov_b = f3s(0);
+    uint32_t bounce = 0;
+    float prev_pdf = -1.0f;
+    while (true) {
+        int info;
+        c_rays++;
+        const int hslot = trav_run_closest<false>(S, s_stack, spill, s_stack2, ray, __builtin_inff(), info, c_nodes, c_tris);
+        ErTraceRec* rec = nrec < max_recs ? &recs[nrec++] : nullptr;
+        if (rec) {
+            rec->bounce = (int32_t)bounce;
+            rec->tri = hslot < 0 ? -1 : __builtin_bit_cast(int, S.tri_isect[(size_t)hslot * 3].w);
+            rec->shadow_tri = -1; rec->opaque = 0; rec->shadow_occ = -1; rec->light_occ = -1;
+            for (int k = 0; k < 3; k++) { rec->position[k] = 0; rec->wi[k] = 0; }
+            if (hslot >= 0) {
+                HitFull h;
+                full_hit(S, (uint32_t)hslot, ray, h);
+                rec->position[0] = h.position.x; rec->position[1] = h.position.y; rec->position[2] = h.position.z;
+            }
+        }
+        BounceOut bo;
+        PixelSink sink{S, s_stack, spill, s_stack2, light, aov_n, aov_t, aov_b, rec, c_rays, c_nodes, c_tris};
+        bounce_step<false, EXT>(S, ray, hslot, rs, light, reduction, bounce, prev_pdf, bo, sink, c_shaded, c_texels, c_hdri);
+        if (rec) {
+            rec->opaque = bo.opaque ? 1 : 0;
+            if (hslot >= 0) { rec->wi[0] = bo.next.d.x; rec->wi[1] = bo.next.d.y; rec->wi[2] = bo.next.d.z; }
+            rec->light[0] = light.x; rec->light[1] = light.y; rec->light[2] = light.z;
+            rec->reduction[0] = reduction.x; rec->reduction[1] = reduction.y; rec->reduction[2] = reduction.z;
+        }
+        if (bo.done) break;
+        ray = bo.next;
+    }
+    const uint32_t sa = S.samples[idx];
+    const uint32_t sa2 = accumulate_sample(S, idx, sa, light, aov_n, aov_t, aov_b);
+    if (sa2 != sa) S.samples[idx] = sa2;
+    S.rng[idx] = rs;
+    *count = nrec;
+    atomicAdd(&S.counters->paths, 1ull);
+    atomicAdd(&S.counters->bounce_samples, (unsigned long long)(bounce + (bounce < S.max_bounces ? 1u : 0u)));
+    atomicAdd(&S.counters->rays, (unsigned long long)c_rays);
+    atomicAdd(&S.counters->shaded_hits, (unsigned long long)c_shaded);
+    atomicAdd(&S.counters->hdri_samples, (unsigned long long)c_hdri);
+}
+
+void er_launch_debug_pixel(const DevScene& S, uint32_t idx, ErTraceRec* recs, int max_recs, int* count, void* spill, hipStream_t stream) {
+    if (er_ext_active(S)) hipLaunchKernelGGL(er_debug_pixel_kernel<true>, dim3(1), dim3(64), 0, stream, S, idx, recs, max_recs, count, (uint2*)spill);
+    else hipLaunchKernelGGL(er_debug_pixel_kernel<false>, dim3(1), dim3(64), 0, stream, S, idx, recs, max_recs, count, (uint2*)spill);
+}
+
+// ---- streaming kernels for the measured HBM peak ("measured peak from a device-to-device copy / triad
+// kernel run in the same job").  Grid-stride over float4, 4 independent 16-byte accesses in flight per lane. ----
+typedef float VF4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void er_hbm_copy_kernel(const VF4* __restrict__ src, VF4* __restrict__ dst, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const VF4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const VF4 c = __builtin_nontemporal_load(src + i + 2 * stride), e = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride);
+        __builtin_nontemporal_store(e, dst + i + 3 * stride);
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void er_hbm_read_kernel(const VF4* __restrict__ src, float* __restrict__ sink, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.0f;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        const VF4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const VF4 c = __builtin_nontemporal_load(src + i + 2 * stride), e = __builtin_nontemporal_load(src + i + 3 * stride);
+        acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (e.x + e.y + e.z + e.w);
+    }
+    for (; i < n; i += stride) { const VF4 a = src[i]; acc += a.x + a.y + a.z + a.w; }
+    if (acc == 1.2345e-30f) sink[0] = acc;     // (never true for the probe's data: keeps the loads alive)
+}
+void er_launch_hbm_copy(const float4* src, float4* dst, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(er_hbm_copy_kernel, dim3(256 * 16), dim3(256), 0, stream, (const VF4*)src, (VF4*)dst, n);
+}
+void er_launch_hbm_read(const float4* src, float* sink, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(er_hbm_read_kernel, dim3(256 * 16), dim3(256), 0, stream, (const VF4*)src, sink, n);
+}

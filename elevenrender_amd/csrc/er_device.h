@@ -48,6 +48,10 @@ struct DevScene {
     ErCamera cam;
     uint32_t x_res, y_res, tiles_x, tiles_y;
     uint32_t max_bounces;
+    // build-defined extensions (er_shade.h): ER_FLAG_POINT_LIGHTS / ER_FLAG_MIS bits of the render flags
+    uint32_t ext_flags;
+    const ErPointLight* lights;
+    uint32_t light_count;
     // per-pixel state
     float4* passes;             // ER_PASS_COUNT planes of x_res*y_res float4
     uint32_t* samples;

@@ -23,6 +23,7 @@
 #include "er_device.h"
 #include "er_kernels.h"
 #include "er_trav.h"
+#include "er_shade.h"
 
 using namespace erd;
 
@@ -53,10 +54,47 @@ __device__ __forceinline__ unsigned fwave_sum(unsigned v) {
 #ifndef FUSED_WAVES
 #define FUSED_WAVES 3
 #endif
-template <bool COUNT>
+// park layout (floats per lane, stride 64): 0-5 next bounce ray (o, d), 6-8 / 9-11 HDRI contribution if visible / if
+// occluded, 12 brdfpdf of the last opaque bounce (ER_FLAG_MIS); LIGHTS only: 13-18 point-light shadow ray (o, d),
+// 19 its limit, 20-22 / 23-25 its contribution if visible / if occluded
+#define PK_NEXT 0
+#define PK_CVIS 6
+#define PK_COCC 9
+#define PK_PDF 12
+#define PK_LRAY 13
+#define PK_LLIM 19
+#define PK_LVIS 20
+#define PK_LOCC 23
+// the fused schedule's sink (er_shade.h): queries and AOVs are parked in the lane's LDS columns
+struct FusedSink {
+    float* park;
+    float* aov;
+    float* job;
+    ERD void hdri_query(const Ray& sr, int self_slot, float d_self, F3 c_vis, F3 c_occ) {
+        job[0] = sr.o.x; job[64] = sr.o.y; job[128] = sr.o.z;
+        job[192] = sr.d.x; job[256] = sr.d.y; job[320] = sr.d.z;
+        job[384] = __builtin_bit_cast(float, self_slot); job[448] = d_self;
+        park[PK_CVIS * 64] = c_vis.x; park[(PK_CVIS + 1) * 64] = c_vis.y; park[(PK_CVIS + 2) * 64] = c_vis.z;
+        park[PK_COCC * 64] = c_occ.x; park[(PK_COCC + 1) * 64] = c_occ.y; park[(PK_COCC + 2) * 64] = c_occ.z;
+    }
+    ERD void light_query(const Ray& lr, float limit, F3 l_vis, F3 l_occ) {
+        park[PK_LRAY * 64] = lr.o.x; park[(PK_LRAY + 1) * 64] = lr.o.y; park[(PK_LRAY + 2) * 64] = lr.o.z;
+        park[(PK_LRAY + 3) * 64] = lr.d.x; park[(PK_LRAY + 4) * 64] = lr.d.y; park[(PK_LRAY + 5) * 64] = lr.d.z;
+        park[PK_LLIM * 64] = limit;
+        park[PK_LVIS * 64] = l_vis.x; park[(PK_LVIS + 1) * 64] = l_vis.y; park[(PK_LVIS + 2) * 64] = l_vis.z;
+        park[PK_LOCC * 64] = l_occ.x; park[(PK_LOCC + 1) * 64] = l_occ.y; park[(PK_LOCC + 2) * 64] = l_occ.z;
+    }
+    ERD void first_hit(F3 n, F3 t, F3 b) {
+        aov[0] = n.x; aov[64] = n.y; aov[128] = n.z;
+        aov[192] = t.x; aov[256] = t.y; aov[320] = t.z;
+        aov[384] = b.x; aov[448] = b.y; aov[512] = b.z;
+    }
+};
+
+template <bool COUNT, bool LIGHTS>   // LIGHTS = the EXT of er_shade.h (point lights and / or MIS)
 __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, uint2* ring_base, uint2* spill_base, uint32_t n_samples) {
     __shared__ uint2 s_stack[WF_LDS_STACK * 64];
-    __shared__ float s_park[12 * 64];      // next bounce ray (o, d) + contribution if visible / if occluded
+    __shared__ float s_park[(LIGHTS ? 26 : 13) * 64];
     __shared__ float s_aov[9 * 64];        // first-bounce normal / tangent / bitangent of the current path
     __shared__ float s_job[8 * 64];        // shadow ray a lane offers to a helper: o, d, bits(slot it leaves), self-hit distance
     __shared__ int s_mail[64];             // helper -> owner: 0 nothing yet, 1 visible, 2 occluded
@@ -72,8 +110,6 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
     volatile int* mail = s_mail;
     s_mail[lane] = 0;
     const uint32_t n_slots = S.owned_tile_count * 64u;
-    const size_t npx = (size_t)S.x_res * S.y_res;
-    const int hw = S.hdri_tex.width, hh = S.hdri_tex.height;
     unsigned c_paths = 0, c_bounce = 0, c_rays = 0, c_nodes = 0, c_tris = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;
 
     Trav T;
@@ -83,6 +119,8 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
     F3 light = f3s(0), reduction = f3s(1);
     bool terminal = false;   // the path is over but its last shadow ray is still being traced
     int occ_code = 0;
+    bool lnext = false;      // LIGHTS: a point-light shadow ray is parked; it is traced after the HDRI one
+    bool lkind = false;      // LIGHTS: the shadow ray this lane is tracing for itself is the point-light one
     // Shadow helpers.  A pixel's samples -- and the bounces of a sample -- are a sequential chain, and when a wave has
     // fewer pixels than lanes (a GPU that owns few pixels; the tail of a call) that chain is all that matters.  Half
     // of it is shadow rays, whose only effect is to select one of two parked contributions: a lane with nothing to
@@ -115,6 +153,29 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     }
+
+    // contribution of this lane's own shadow query (HDRI or point light) by outcome
+    auto own_contribution = [&](bool occluded) {
+        const int b = (LIGHTS && lkind) ? (occluded ? PK_LOCC : PK_LVIS) : (occluded ? PK_COCC : PK_CVIS);
+        return f3(park[b * 64], park[(b + 1) * 64], park[(b + 2) * 64]);
+    };
+    // what follows a finished own shadow query: the parked point-light query, else the end of the path, else the parked ray
+    auto after_own_shadow = [&]() {
+        if (LIGHTS && lnext) {
+            lnext = false;
+            lkind = true;
+            trav_begin(T, f3(park[PK_LRAY * 64], park[(PK_LRAY + 1) * 64], park[(PK_LRAY + 2) * 64]),
+                       f3(park[(PK_LRAY + 3) * 64], park[(PK_LRAY + 4) * 64], park[(PK_LRAY + 5) * 64]), true, -1, park[PK_LLIM * 64]);
+            c_rays++;
+            mode = M_TRACE;
+        } else if (terminal) {
+            mode = M_FINALIZE;
+        } else {
+            trav_begin(T, f3(park[0], park[64], park[128]), f3(park[192], park[256], park[320]), false, -1, __builtin_inff());
+            c_rays++;
+            mode = M_TRACE;
+        }
+    };
 
     while (true) {
         // (pixels are handed out inside the batch, right after the lanes that finished a sample put theirs back)
@@ -155,131 +216,54 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
                         owner = -1;
                         mode = M_IDLE;
                     } else {
-                    light = light + (occ ? f3(park[9 * 64], park[10 * 64], park[11 * 64]) : f3(park[6 * 64], park[7 * 64], park[8 * 64]));
-                    if (terminal) {
-                        fin = true;
-                    } else {
-                        trav_begin(T, f3(park[0], park[64], park[128]), f3(park[192], park[256], park[320]), false, -1, __builtin_inff());
-                        c_rays++;
-                        mode = M_TRACE;
+                    light = light + own_contribution(occ);
+                    after_own_shadow();
+                    if (mode == M_FINALIZE) fin = true;
                     }
-                    }
-                } else {   // M_SHADE: one iteration of the bounce loop
+                } else {   // M_SHADE: one iteration of the bounce loop (er_shade.h)
                     Ray ray;
                     ray.o = T.o; ray.d = T.d;
-                    int hslot = resolve_closest<COUNT>(S, stack2, ray, T.s0 >= 0 ? T.s0 : T.s1,
-                                                       T.overflow ? -2 : ((T.s0 >= 0 && T.s1 >= 0) ? T.s1 : -1), c_nodes, c_tris);
+                    const int hslot = resolve_closest<COUNT>(S, stack2, ray, T.s0 >= 0 ? T.s0 : T.s1,
+                                                             T.overflow ? -2 : ((T.s0 >= 0 && T.s1 >= 0) ? T.s1 : -1), c_nodes, c_tris);
                     c_bounce++;
-                    bool done = false, pending = false;
-                    if (hslot < 0) {
-                        float u, v;
-                        spherical_mapping(-1 * ray.d, u, v);
-                        light = light + reduction * tex_filtered(S, S.hdri_tex, u, v);
-                        if (COUNT) c_texels++;
-                        done = true;
-                    } else {
-                        c_shaded++;
-                        HitFull hit;
-                        full_hit(S, (uint32_t)hslot, ray, hit);
-                        const ErMaterial& mat = S.materials[hit.material];
-                        HitData hd;
-                        generate_hit_data<COUNT>(S, mat, hit, hd, c_texels);
-                        int shader = mat.albedo_shader_id;
-                        if (shader != -1) {   // asl_shade placeholder, src/shader.cpp:6-10
-                            hd.albedo = f3s(0);
-                            if (shader >= 0 && shader < 4) hd.albedo = f3(1, 1, 0);
-                        }
-                        Ray sr;
-                        sr.o = f3s(0); sr.d = f3(0, 0, 1);
-                        float d_self = __builtin_inff();
-                        if (rng_next(rs) <= hd.opacity) {
-                            F3 wo = ray.d * -1.0f;
-                            F3 N = hd.normal;
-                            c_hdri++;
-                            int count = er_cdf_search(S.hdri_cdf, hw * hh, S.hdri_guide, S.hdri_buckets, rng_next(rs));   // == HDRI::binarySearch
-                            float tcx = (float)(count % hw), tcy = (float)(count / hw);
-                            float d1 = rng_next(rs), d2 = rng_next(rs), d3 = rng_next(rs);
-                            F3 wibrdf = DisneySample(hd, wo, N, d1, d2, d3);
-                            float nu = tcx / (float)hw, nv = tcy / (float)hh;
-                            float iu, iv;
-                            inverse_transform_uv(S.hdri_tex, nu, nv, iu, iv);
-                            F3 wihdri = normalized(reverse_spherical_mapping(iu, iv)) * -1.0f;
-                            F3 hdriValue = tex_uv(S, S.hdri_tex, iu, iv);
-                            if (COUNT) c_texels += 2;
-                            F3 evalh = DisneyEval(hd, wo, N, wihdri);
-                            float hdripdf = hdri_pdf(S, ermath::f2i(iu * hw), ermath::f2i(iv * hh));
-                            float absdot = __builtin_fabsf(dot(wihdri, N));
-                            F3 c_vis = reduction * (hd.emission + hdriValue * evalh * absdot / hdripdf);
-                            if (evalh.x != 0.0f || evalh.y != 0.0f || evalh.z != 0.0f) {
-                                // shadow query needed (er_kernels.hip): occluded iff the closest hit is another triangle
-                                F3 c_occ = reduction * (hd.emission + f3s(0) * evalh * absdot / hdripdf);
-                                sr = make_ray(hd.position + N * 0.001f, wihdri);
-                                F3 v0, v1, v2;
-                                float4 qa, qb, qc4;
-                                load_verts(S, (uint32_t)hslot, v0, v1, v2, qa, qb, qc4);
-                                float su, sv, st;
-                                if (tri_mt(v0, v1, v2, sr, su, sv, st)) d_self = candidate_distance(S, (uint32_t)hslot, v0, v1, v2, sr, su, sv, st);
-                                park[6 * 64] = c_vis.x; park[7 * 64] = c_vis.y; park[8 * 64] = c_vis.z;
-                                park[9 * 64] = c_occ.x; park[10 * 64] = c_occ.y; park[11 * 64] = c_occ.z;
-                                pending = true;
-                            } else {
-                                light = light + c_vis;
-                            }
-                            float brdfpdf = DisneyPdf(hd, wo, N, wibrdf);
-                            reduction = reduction * (DisneyEval(hd, wo, N, wibrdf) * __builtin_fabsf(dot(wibrdf, N)) / brdfpdf);
-                            if (bounce == 0) {
-                                aov[0] = hd.normal.x; aov[64] = hd.normal.y; aov[128] = hd.normal.z;
-                                aov[192] = hd.tangent.x; aov[256] = hd.tangent.y; aov[320] = hd.tangent.z;
-                                aov[384] = hd.bitangent.x; aov[448] = hd.bitangent.y; aov[512] = hd.bitangent.z;
-                            }
-                            ray = make_ray(hit.position + wibrdf * 0.001f, wibrdf);
+                    float prev_pdf = LIGHTS ? park[PK_PDF * 64] : -1.0f;
+                    BounceOut bo;
+                    FusedSink sink{park, aov, s_job + lane};
+                    bounce_step<COUNT, LIGHTS>(S, ray, hslot, rs, light, reduction, bounce, prev_pdf, bo, sink, c_shaded, c_texels, c_hdri);
+                    if (LIGHTS) park[PK_PDF * 64] = prev_pdf;
+                    const bool lsh = LIGHTS && bo.lshadow;
+                    if (bo.shadow || lsh) {
+                        // trace the shadow ray(s) first; the next bounce ray waits in LDS
+                        park[0] = bo.next.o.x; park[64] = bo.next.o.y; park[128] = bo.next.o.z;
+                        park[192] = bo.next.d.x; park[256] = bo.next.d.y; park[320] = bo.next.d.z;
+                        terminal = bo.done;
+                        if (bo.shadow) {
+                            lnext = lsh;
+                            lkind = false;
+                            const float* job = s_job + lane;     // the sink left the HDRI shadow ray here
+                            trav_begin(T, f3(job[0], job[64], job[128]), f3(job[192], job[256], job[320]), true, __builtin_bit_cast(int, job[384]), job[448]);
+                            c_rays++;
+                            mode = M_TRACE;
+                            // offer the HDRI shadow ray to a free lane (below); taken -> this lane traces the parked ray now.
+                            // (Not when a point-light query follows: its contribution must be added after the HDRI one.)
+                            offer = !bo.done && !lsh;
                         } else {
-                            ray = make_ray(hit.position + ray.d * 0.001f, ray.d);
+                            lnext = true;
+                            after_own_shadow();     // starts the point-light query
                         }
-                        bounce++;
-                        if (bounce >= S.max_bounces) done = true;
-                        if (pending) {
-                            // trace the shadow ray first; the next bounce ray waits in LDS
-                            park[0] = ray.o.x; park[64] = ray.o.y; park[128] = ray.o.z;
-                            park[192] = ray.d.x; park[256] = ray.d.y; park[320] = ray.d.z;
-                            trav_begin(T, sr.o, sr.d, true, hslot, d_self);
-                            c_rays++;
-                            terminal = done;
-                            mode = M_TRACE;
-                            if (!done) {   // offer the shadow ray to a free lane (below); taken -> this lane traces the parked ray now
-                                float* job = s_job + lane;
-                                job[0] = sr.o.x; job[64] = sr.o.y; job[128] = sr.o.z;
-                                job[192] = sr.d.x; job[256] = sr.d.y; job[320] = sr.d.z;
-                                job[384] = __builtin_bit_cast(float, hslot); job[448] = d_self;
-                                offer = true;
-                            }
-                        } else if (!done) {
-                            trav_begin(T, ray.o, ray.d, false, -1, __builtin_inff());
-                            c_rays++;
-                            mode = M_TRACE;
-                        }
+                    } else if (!bo.done) {
+                        trav_begin(T, bo.next.o, bo.next.d, false, -1, __builtin_inff());
+                        c_rays++;
+                        mode = M_TRACE;
+                    } else {
+                        fin = true;
                     }
-                    if (done && !pending) fin = true;
                 }
                 if (fin) {
-                    // src/kernel.cpp:597-645: clamp, NaN gate, running mean over sa (starts at 1)
-                    light = f3(clampf(light.x, 0, 10), clampf(light.y, 0, 10), clampf(light.z, 0, 10));
-                    uint32_t sa = S.samples[idx];
-                    if (!(light.x != light.x) && !(light.y != light.y) && !(light.z != light.z)) {
-                        float k = ((float)sa) / ((float)(sa + 1));
-                        float inv = (float)(sa + 1);
-                        const F3 vals[4] = {light, f3(aov[0], aov[64], aov[128]), f3(aov[192], aov[256], aov[320]), f3(aov[384], aov[448], aov[512])};
-                        const int planes[4] = {ER_PASS_BEAUTY, ER_PASS_NORMAL, ER_PASS_TANGENT, ER_PASS_BITANGENT};
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            float4* pp = S.passes + (size_t)planes[q] * npx + idx;
-                            float4 p = *pp;
-                            if (sa > 0) { p.x *= k; p.y *= k; p.z *= k; }
-                            p.x += vals[q].x / inv; p.y += vals[q].y / inv; p.z += vals[q].z / inv;
-                            *pp = p;
-                        }
-                        S.samples[idx] = sa + 1;
-                    }
+                    const uint32_t sa = S.samples[idx];
+                    const uint32_t sa2 = accumulate_sample(S, idx, sa, light, f3(aov[0], aov[64], aov[128]), f3(aov[192], aov[256], aov[320]),
+                                                           f3(aov[384], aov[448], aov[512]));   // src/kernel.cpp:597-645
+                    if (sa2 != sa) S.samples[idx] = sa2;
                     S.rng[idx] = rs;
                     c_paths++;
                     left--;
@@ -345,6 +329,7 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
                 reduction = f3s(1);
                 bounce = 0;
                 terminal = false;
+                if (LIGHTS) park[PK_PDF * 64] = -1.0f;
 #pragma unroll
                 for (int q = 0; q < 9; q++) aov[q * 64] = 0.0f;
                 trav_begin(T, ray.o, ray.d, false, -1, __builtin_inff());
@@ -377,13 +362,8 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
                         mode = M_IDLE;
                     } else if (code <= 1) {
                         // the shadow query's outcome only selects which precomputed contribution is added
-                        light = light + (code ? f3(park[9 * 64], park[10 * 64], park[11 * 64]) : f3(park[6 * 64], park[7 * 64], park[8 * 64]));
-                        if (terminal) {
-                            mode = M_FINALIZE;
-                        } else {
-                            trav_begin(T, f3(park[0], park[64], park[128]), f3(park[192], park[256], park[320]), false, -1, __builtin_inff());
-                            c_rays++;
-                        }
+                        light = light + own_contribution(code != 0);
+                        after_own_shadow();
                     } else {
                         occ_code = code;
                         mode = M_RESOLVE;
@@ -409,8 +389,18 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
     }
 }
 
+hipError_t er_probe_fused(const char** which) {
+    hipFuncAttributes a;
+    *which = "er_fused_kernel";
+    hipError_t e = hipFuncGetAttributes(&a, (const void*)er_fused_kernel<false, false>);
+    if (e != hipSuccess) return e;
+    return hipFuncGetAttributes(&a, (const void*)er_fused_kernel<false, true>);
+}
+
 void er_launch_fused(const DevScene& S, void* ring, void* spill, uint32_t n_samples, bool count, uint32_t blocks, hipStream_t stream) {
     if (S.owned_tile_count == 0 || n_samples == 0) return;
-    if (count) hipLaunchKernelGGL(er_fused_kernel<true>, dim3(blocks), dim3(64), 0, stream, S, (uint2*)ring, (uint2*)spill, n_samples);
-    else hipLaunchKernelGGL(er_fused_kernel<false>, dim3(blocks), dim3(64), 0, stream, S, (uint2*)ring, (uint2*)spill, n_samples);
+    const bool lights = er_ext_active(S);   // bigger LDS park area
+    auto k = count ? (lights ? er_fused_kernel<true, true> : er_fused_kernel<true, false>)
+                   : (lights ? er_fused_kernel<false, true> : er_fused_kernel<false, false>);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64), 0, stream, S, (uint2*)ring, (uint2*)spill, n_samples);
 }

@@ -579,6 +579,12 @@ struct GpuBuild {
 
 }  // namespace
 
+hipError_t er_probe_gpu_build(const char** which) {   // see er_kernels.h
+    hipFuncAttributes at;
+    *which = "k_scene_bounds (er_gpu_build.hip)";
+    return hipFuncGetAttributes(&at, (const void*)k_scene_bounds);
+}
+
 int er_gpu_build_device(const ErGpuSceneArrays& a, uint32_t n, int device, ErGpuBvhDevice* out, std::string& err) {
     auto t0 = std::chrono::steady_clock::now();
     if (n <= ER_BVH_LEAF_MAX) { err = "too few triangles for the device builder"; return 1; }

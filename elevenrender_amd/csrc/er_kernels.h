@@ -6,6 +6,12 @@
 struct DevScene;
 
 void er_launch_setup(const DevScene& S, hipStream_t stream);
+// hipFuncGetAttributes on one kernel of every translation unit: hipSuccess iff the loaded library carries code this
+// device can run (*which names the first kernel that failed).  Called by er_render_begin before the first launch.
+hipError_t er_probe_kernels(const char** which);
+hipError_t er_probe_wavefront(const char** which);
+hipError_t er_probe_fused(const char** which);
+hipError_t er_probe_gpu_build(const char** which);
 void er_launch_atrous(const float4* src, const float4* normal, float4* dst, int w, int h, int step, float kc, hipStream_t stream);
 void er_launch_debug_hit(const DevScene& S, const float* o, const float* d, uint32_t n, int32_t* tri, float* pos, float* dist, hipStream_t stream);
 void er_launch_render(const DevScene& S, uint32_t n_samples, bool count, hipStream_t stream);

@@ -9,6 +9,7 @@
 // until a lane has finished all n samples instead of idling to the longest path.
 #include "er_kernels.h"
 #include "er_device.h"
+#include "er_shade.h"
 
 using namespace erd;
 
@@ -30,7 +31,30 @@ __global__ void er_setup_kernel(DevScene S) {
     S.samples[idx] = 1;
 }
 
+// the megakernel's sink (er_shade.h): shadow rays are traced at once through the exact binary-BVH routine
 template <bool COUNT>
+struct MegaSink {
+    const DevScene& S;
+    int* stack;
+    F3& light;
+    F3 &aov_n, &aov_t, &aov_b;
+    unsigned &c_rays, &c_nodes, &c_tris;
+    ERD void hdri_query(const Ray& sr, int self_slot, float d_self, F3 c_vis, F3 c_occ) {
+        float sd;     // occluded iff the closest hit is another triangle (src/kernel.cpp:555-562)
+        c_rays++;
+        const int occ = trace<COUNT, true>(S, stack, sr, self_slot, d_self, sd, c_nodes, c_tris);
+        light = light + (occ >= 0 ? c_occ : c_vis);
+    }
+    ERD void light_query(const Ray& lr, float limit, F3 l_vis, F3 l_occ) {
+        float sd;     // point-light sample (ER_FLAG_POINT_LIGHTS): occluded iff a hit is nearer than the light
+        c_rays++;
+        const int occ = trace<COUNT, true>(S, stack, lr, -1, limit, sd, c_nodes, c_tris);
+        light = light + (occ >= 0 ? l_occ : l_vis);
+    }
+    ERD void first_hit(F3 n, F3 t, F3 b) { aov_n = n; aov_t = t; aov_b = b; }
+};
+
+template <bool COUNT, bool EXT>
 __global__ __launch_bounds__(64) void er_render_kernel(DevScene S, uint32_t n_samples) {
     __shared__ int s_stack[ER_STACK * 64];
     const int lane = threadIdx.x;
@@ -42,13 +66,12 @@ __global__ __launch_bounds__(64) void er_render_kernel(DevScene S, uint32_t n_sa
 
     if (px < S.x_res && py < S.y_res && n_samples > 0) {
         const uint32_t idx = py * S.x_res + px;
-        const size_t npx = (size_t)S.x_res * S.y_res;
         uint32_t rs = S.rng[idx];
         uint32_t sa = S.samples[idx];
-        const int hw = S.hdri_tex.width, hh = S.hdri_tex.height;
 
         uint32_t s = 0;
         uint32_t bounce = 0;
+        float prev_pdf = -1.0f;
         bool fresh = true;
         Ray ray;
         F3 light, reduction, aov_n, aov_t, aov_b;
@@ -59,93 +82,21 @@ __global__ __launch_bounds__(64) void er_render_kernel(DevScene S, uint32_t n_sa
                 ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
                 light = f3s(0); reduction = f3s(1); aov_n = f3s(0); aov_t = f3s(0); aov_b = f3s(0);
                 bounce = 0;
+                prev_pdf = -1.0f;
                 fresh = false;
             }
-            // ---- one iteration of the bounce loop, src/kernel.cpp:508-593 ----
+            // ---- one iteration of the bounce loop, src/kernel.cpp:508-593 (er_shade.h), rays traced inline ----
             c_bounce++;
-            bool done = false;
             float dist;
             c_rays++;
-            int slot = trace<COUNT, false>(S, stack, ray, -1, __builtin_inff(), dist, c_nodes, c_tris);
-            if (slot < 0) {
-                float u, v;
-                spherical_mapping(-1 * ray.d, u, v);
-                light = light + reduction * tex_filtered(S, S.hdri_tex, u, v);
-                if (COUNT) c_texels++;
-                done = true;
-            } else {
-                c_shaded++;
-                HitFull hit;
-                full_hit(S, (uint32_t)slot, ray, hit);
-                const ErMaterial& mat = S.materials[hit.material];
-                HitData hd;
-                generate_hit_data<COUNT>(S, mat, hit, hd, c_texels);
-                int shader = mat.albedo_shader_id;
-                if (shader != -1) {   // asl_shade placeholder, src/shader.cpp:6-10, src/shader.h:10-11
-                    hd.albedo = f3s(0);
-                    if (shader >= 0 && shader < 4) hd.albedo = f3(1, 1, 0);
-                }
-                if (rng_next(rs) <= hd.opacity) {
-                    F3 wo = ray.d * -1.0f;
-                    F3 N = hd.normal;
-                    c_hdri++;
-                    int count = hdri_binary_search(S.hdri_cdf, rng_next(rs), hw * hh);   // HDRI::sample
-                    float tcx = (float)(count % hw), tcy = (float)(count / hw);
-                    float d1 = rng_next(rs), d2 = rng_next(rs), d3 = rng_next(rs);
-                    F3 wibrdf = DisneySample(hd, wo, N, d1, d2, d3);
-                    float nu = tcx / (float)hw, nv = tcy / (float)hh;
-                    float iu, iv;
-                    inverse_transform_uv(S.hdri_tex, nu, nv, iu, iv);
-                    F3 wihdri = normalized(reverse_spherical_mapping(iu, iv)) * -1.0f;
-                    F3 hdriValue = tex_uv(S, S.hdri_tex, iu, iv);
-                    if (COUNT) c_texels += 2;
-                    F3 evalh = DisneyEval(hd, wo, N, wihdri);
-                    // The reference always traces the shadow ray (src/kernel.cpp:555-562).  When the
-                    // BRDF term is exactly zero the product below is the same for either outcome, so
-                    // the query is skipped; otherwise: occluded iff the closest hit is another triangle.
-                    if (evalh.x != 0.0f || evalh.y != 0.0f || evalh.z != 0.0f) {
-                        Ray sr = make_ray(hd.position + N * 0.001f, wihdri);
-                        F3 v0, v1, v2;
-                        float4 qa, qb, qc;
-                        load_verts(S, (uint32_t)slot, v0, v1, v2, qa, qb, qc);
-                        float su, sv, st, d_self = __builtin_inff();
-                        if (tri_mt(v0, v1, v2, sr, su, sv, st)) d_self = candidate_distance(S, (uint32_t)slot, v0, v1, v2, sr, su, sv, st);
-                        float sd;
-                        c_rays++;
-                        int occ = trace<COUNT, true>(S, stack, sr, slot, d_self, sd, c_nodes, c_tris);
-                        if (occ >= 0) hdriValue = f3s(0);
-                    }
-                    float hdripdf = hdri_pdf(S, ermath::f2i(iu * hw), ermath::f2i(iv * hh));
-                    F3 hdriInt = hdriValue * evalh * __builtin_fabsf(dot(wihdri, N)) / hdripdf;
-                    float brdfpdf = DisneyPdf(hd, wo, N, wibrdf);
-                    light = light + reduction * (hd.emission + hdriInt);
-                    reduction = reduction * (DisneyEval(hd, wo, N, wibrdf) * __builtin_fabsf(dot(wibrdf, N)) / brdfpdf);
-                    if (bounce == 0) { aov_n = hd.normal; aov_t = hd.tangent; aov_b = hd.bitangent; }
-                    ray = make_ray(hit.position + wibrdf * 0.001f, wibrdf);
-                } else {
-                    ray = make_ray(hit.position + ray.d * 0.001f, ray.d);
-                }
-                bounce++;
-                if (bounce >= S.max_bounces) done = true;
-            }
+            const int slot = trace<COUNT, false>(S, stack, ray, -1, __builtin_inff(), dist, c_nodes, c_tris);
+            BounceOut o;
+            MegaSink<COUNT> sink{S, stack, light, aov_n, aov_t, aov_b, c_rays, c_nodes, c_tris};
+            bounce_step<COUNT, EXT>(S, ray, slot, rs, light, reduction, bounce, prev_pdf, o, sink, c_shaded, c_texels, c_hdri);
+            ray = o.next;
+            const bool done = o.done;
             if (done) {
-                // src/kernel.cpp:597-645: clamp, NaN gate, running mean over sa (starts at 1)
-                light = f3(clampf(light.x, 0, 10), clampf(light.y, 0, 10), clampf(light.z, 0, 10));
-                if (!(light.x != light.x) && !(light.y != light.y) && !(light.z != light.z)) {
-                    float k = ((float)sa) / ((float)(sa + 1));
-                    float inv = (float)(sa + 1);
-                    const F3 vals[4] = {light, aov_n, aov_t, aov_b};
-                    const int planes[4] = {ER_PASS_BEAUTY, ER_PASS_NORMAL, ER_PASS_TANGENT, ER_PASS_BITANGENT};
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        float4* pp = S.passes + (size_t)planes[q] * npx + idx;
-                        float4 p = *pp;
-                        if (sa > 0) { p.x *= k; p.y *= k; p.z *= k; }
-                        p.x += vals[q].x / inv; p.y += vals[q].y / inv; p.z += vals[q].z / inv;
-                        *pp = p;
-                    }
-                    sa++;
-                }
+                sa = accumulate_sample(S, idx, sa, light, aov_n, aov_t, aov_b);   // src/kernel.cpp:597-645
                 c_paths++;
                 s++;
                 fresh = true;
@@ -218,6 +169,20 @@ void er_launch_debug_hit(const DevScene& S, const float* o, const float* d, uint
     hipLaunchKernelGGL(er_debug_hit_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, S, o, d, n, tri, pos, dist);
 }
 
+hipError_t er_probe_kernels(const char** which) {
+    hipFuncAttributes a;
+    hipError_t e;
+    *which = "er_setup_kernel";
+    if ((e = hipFuncGetAttributes(&a, (const void*)er_setup_kernel)) != hipSuccess) return e;
+    *which = "er_render_kernel";
+    if ((e = hipFuncGetAttributes(&a, (const void*)er_render_kernel<false, false>)) != hipSuccess) return e;
+    if ((e = er_probe_wavefront(which)) != hipSuccess) return e;
+    if ((e = er_probe_fused(which)) != hipSuccess) return e;
+    if ((e = er_probe_gpu_build(which)) != hipSuccess) return e;
+    *which = nullptr;
+    return hipSuccess;
+}
+
 void er_launch_setup(const DevScene& S, hipStream_t stream) {
     uint32_t npx = S.x_res * S.y_res;
     if (npx == 0) return;
@@ -225,8 +190,9 @@ void er_launch_setup(const DevScene& S, hipStream_t stream) {
 }
 void er_launch_render(const DevScene& S, uint32_t n_samples, bool count, hipStream_t stream) {
     if (S.owned_tile_count == 0 || n_samples == 0) return;
-    if (count) hipLaunchKernelGGL(er_render_kernel<true>, dim3(S.owned_tile_count), dim3(64), 0, stream, S, n_samples);
-    else hipLaunchKernelGGL(er_render_kernel<false>, dim3(S.owned_tile_count), dim3(64), 0, stream, S, n_samples);
+    const bool ext = er_ext_active(S);
+    auto k = count ? (ext ? er_render_kernel<true, true> : er_render_kernel<true, false>) : (ext ? er_render_kernel<false, true> : er_render_kernel<false, false>);
+    hipLaunchKernelGGL(k, dim3(S.owned_tile_count), dim3(64), 0, stream, S, n_samples);
 }
 // ---- denoise: edge-avoiding a-trous wavelet filter of the BEAUTY plane, guided by colour and
 // by the first-bounce NORMAL plane, into the DENOISE plane that the reference allocates but never writes (reference

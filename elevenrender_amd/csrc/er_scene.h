@@ -1,0 +1,261 @@
+// er_scene.h -- host-side state behind the opaque ErScene handle of include/eleven_hip.h, and the small helpers the
+// translation units of the boundary share (er_api.cpp: the drop-in entry points; er_debug_api.cpp: inspection hooks of
+// include/eleven_hip_debug.h; er_collective.cpp: the RCCL framebuffer combine).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/eleven_hip.h"
+#include "er_bvh.h"
+#include "er_device.h"
+#include "er_gpu_build.h"
+#include "er_kernels.h"
+#include "er_wavefront.h"
+
+namespace erh {
+
+
+inline thread_local std::string g_err;
+
+inline int fail(int code, const std::string& msg) noexcept {
+    try { g_err = msg; } catch (...) { /* keeping the previous text beats unwinding through the C ABI */ }
+    return code;
+}
+
+// Every extern "C" entry point runs its body through this: the header promises "never throws", and the bodies
+// allocate (std::vector, std::string, std::map) -- a std::bad_alloc must come back as ER_ERR_OOM, not unwind
+// through the C ABI into a host that may not even be C++ (reference: errors are logged and never propagated,
+// src/Managers.cpp:244-246).
+template <class F>
+int guarded(const char* who, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(ER_ERR_OOM, std::string(who) + ": out of host memory");
+    } catch (const std::exception& e) {
+        return fail(ER_ERR_STATE, std::string(who) + ": " + e.what());
+    } catch (...) {
+        return fail(ER_ERR_STATE, std::string(who) + ": unknown exception");
+    }
+}
+
+// Test hook (include/eleven_hip_debug.h, er_debug_set_host_alloc_limit): the library's large host allocations
+// announce their size here first, so the out-of-memory path can be exercised without exhausting the machine.
+inline std::atomic<uint64_t> g_host_alloc_limit{0};
+inline void host_reserve(uint64_t bytes) {
+    const uint64_t lim = g_host_alloc_limit.load();
+    if (lim && bytes > lim) throw std::bad_alloc();
+}
+
+struct EventPair {      // two timing events that do not outlive the function that made them
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(e__ == hipErrorOutOfMemory ? ER_ERR_OOM : ER_ERR_HIP,                           \
+                        std::string(#expr) + ": " + hipGetErrorString(e__));                            \
+    } while (0)
+
+struct HostTex {
+    int32_t width, height, channels, filter;
+    std::vector<float> data;
+};
+
+// Texture::getValueFromCoordinates, reference src/Texture.cpp:172-200 (host copy, used by the CDF)
+inline void host_tex_coords(const HostTex& t, int x, int y, float out[3]) {
+    x %= t.width;
+    y %= t.height;
+    if (x < 0) x *= -1;
+    if (y < 0) y *= -1;
+    out[0] = out[1] = out[2] = 0.0f;
+    const float* d = t.data.data();
+    if (t.channels == 1) {
+        out[0] = out[1] = out[2] = d[y * t.width + x];
+    } else if (t.channels == 2) {
+        out[0] = d[t.channels * (y * t.width + x) + 0];
+        out[1] = d[t.channels * (y * t.width + x) + 1];
+    } else if (t.channels >= 3) {
+        out[0] = d[t.channels * (y * t.width + x) + 0];
+        out[1] = d[t.channels * (y * t.width + x) + 1];
+        out[2] = d[t.channels * (y * t.width + x) + 2];
+    }
+}
+
+// HDRI::generateCDF, reference src/HDRI.cpp:62-83 (host preparation, same float sequence)
+inline void host_generate_cdf(const HostTex& t, std::vector<float>& cdf, float& radianceSum) {
+    int c = 0;
+    radianceSum = 0;
+    cdf.assign((size_t)t.width * t.height + 1, 0.0f);
+    float p[3];
+    for (int j = 0; j < t.height; j++)
+        for (int i = 0; i < t.width; i++) {
+            host_tex_coords(t, i, j, p);
+            radianceSum += p[0] + p[1] + p[2];
+        }
+    for (int j = 0; j < t.height; j++)
+        for (int i = 0; i < t.width; i++) {
+            host_tex_coords(t, i, j, p);
+            cdf[c + 1] = cdf[c] + (p[0] + p[1] + p[2]) / radianceSum;
+            c++;
+        }
+}
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+};
+
+template <class T>
+struct ScopedDevBuf : DevBuf<T> {   // a temporary: freed on every way out of the function
+    ScopedDevBuf() = default;
+    ScopedDevBuf(const ScopedDevBuf&) = delete;
+    ScopedDevBuf& operator=(const ScopedDevBuf&) = delete;
+    ~ScopedDevBuf() { this->release(); }
+};
+
+
+}  // namespace erh
+
+using erh::DevBuf;
+using erh::HostTex;
+
+struct ErScene {
+    // host copy of the description
+    uint32_t tri_count = 0;
+    std::vector<float> vertices, normals, tangents, uvs, tangent_sign;
+    std::vector<int32_t> material_id;
+    std::vector<ErMaterial> materials;
+    std::vector<HostTex> textures;
+    HostTex hdri_tex;
+    std::vector<float> hdri_cdf;
+    float hdri_radiance_sum = 0;
+    ErCamera camera;
+    std::vector<ErPointLight> point_lights;
+    uint32_t x_res = 0, y_res = 0;
+
+    // render state
+    bool begun = false;
+    int device = 0;
+    ErRenderParams params{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timing_open = false;
+    DevScene dev{};
+    ErAccelInfo accel{};
+    DevBuf<float4> d_nodes, d_nodes8, d_isect, d_attr, d_passes;
+    DevBuf<ErMaterial> d_materials;
+    DevBuf<ErPointLight> d_lights;
+    DevBuf<DevTex> d_textures;
+    DevBuf<float> d_tex_pool, d_cdf;
+    DevBuf<uint32_t> d_samples, d_rng, d_owned;
+    DevBuf<DevCounters> d_counters;
+    DevBuf<float4> d_wf4;        // 11 float4 arrays of the wavefront state, back to back
+    DevBuf<uint32_t> d_wf1;      // hit, left, occluded, 4 queues, counts
+    DevBuf<uint2> d_spill;
+    DevBuf<uint32_t> d_guide, d_ticket;
+    uint32_t fused_blocks = 0;
+    std::vector<WfState> wf;              // slot pools (see er_render_begin)
+    std::vector<hipStream_t> pool_streams;   // pool 0 runs on `stream`, pool p > 0 on pool_streams[p - 1]
+    std::vector<hipEvent_t> pool_events;     // [0] fork; [p] pool p has finished
+
+    uint32_t trace_blocks = 0, shade_blocks = 0;
+    std::vector<hipEvent_t> prof_events;   // ER_FLAG_PROFILE: e[3i], e[3i+1], e[3i+2] = before trace, between, after shade
+    DevBuf<uint32_t> d_ray_log;            // ER_FLAG_PROFILE, wavefront: rays found by the i-th trace launch (same order)
+    size_t prof_used = 0;
+    ErProfile profile{};
+    std::map<uint32_t, DevBuf<uint32_t>> d_rank_tiles;   // tile lists of other ranks (for unpack)
+    std::mutex mtx;
+
+    std::vector<uint32_t> tiles_of(uint32_t rank, uint32_t world) const {
+        std::vector<uint32_t> t;
+        uint32_t tiles_x = (x_res + ER_TILE - 1) / ER_TILE, tiles_y = (y_res + ER_TILE - 1) / ER_TILE;
+        for (uint32_t ty = 0; ty < tiles_y; ty++)
+            for (uint32_t tx = 0; tx < tiles_x; tx++)
+                if ((tx + ty) % world == rank) t.push_back(ty * tiles_x + tx);
+        return t;
+    }
+    void release_device() {
+        d_nodes.release(); d_nodes8.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_materials.release();
+        d_textures.release(); d_tex_pool.release(); d_lights.release(); d_cdf.release(); d_samples.release(); d_rng.release();
+        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_ray_log.release();
+        for (auto& kv : d_rank_tiles) kv.second.release();
+        d_rank_tiles.clear();
+        for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
+        prof_events.clear();
+        prof_used = 0;
+        for (hipEvent_t e : pool_events) (void)hipEventDestroy(e);
+        pool_events.clear();
+        for (hipStream_t st : pool_streams) (void)hipStreamDestroy(st);
+        pool_streams.clear();
+        wf.clear();
+        if (ev_start) (void)hipEventDestroy(ev_start);
+        if (ev_stop) (void)hipEventDestroy(ev_stop);
+        if (stream) (void)hipStreamDestroy(stream);
+        ev_start = ev_stop = nullptr;
+        stream = nullptr;
+        begun = false;
+        timing_open = false;
+    }
+};
+
+namespace erh {
+
+// guide table of er_cdf.h: guide[j] = first i in [0,length] with cdf[i] >= j/buckets
+inline int er_build_cdf_guide(const float* cdf, int length, std::vector<uint32_t>& guide) {
+    int buckets = 1;
+    while (buckets < length / 8 && buckets < (1 << 22)) buckets <<= 1;
+    guide.assign((size_t)buckets + 1, (uint32_t)length);
+    int i = 0;
+    for (int j = 0; j <= buckets; j++) {
+        float thr = (float)j / (float)buckets;
+        while (i < length && cdf[i] < thr) i++;
+        guide[j] = (uint32_t)i;
+    }
+    return buckets;
+}
+
+template <class T>
+int upload(DevBuf<T>& b, const void* src, size_t count, hipStream_t s) {
+    b.release();
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void**)&b.p, bytes));
+    b.n = count;
+    if (count && src) HIP_TRY(hipMemcpyAsync(b.p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    return ER_OK;
+}
+
+inline int copy_tex(const ErTexture& in, HostTex& out, const char* what) {
+    if (in.width <= 0 || in.height <= 0 || in.channels < 0 || (in.channels > 0 && !in.data))
+        return fail(ER_ERR_INVALID_ARG, std::string("bad texture: ") + what);
+    out.width = in.width; out.height = in.height; out.channels = in.channels; out.filter = in.filter;
+    size_t n = (size_t)in.width * in.height * in.channels;
+    out.data.assign(in.data, in.data + n);
+    return ER_OK;
+}
+
+
+}  // namespace erh

@@ -298,4 +298,42 @@ ERD bool resolve_shadow(const DevScene& S, int* stack2, const Ray& sr, int self_
     return occ != 0;
 }
 
+// ---- a whole query for ONE lane (debug hooks, er_debug.hip).  The production kernels interleave the steps of many
+// rays (er_wf_trace refills lanes, er_fused_kernel alternates with shading); the steps themselves are these. ----
+template <bool COUNT>
+ERD int trav_run_closest(const DevScene& S, uint2* stack, uint2* spill, int* stack2, const Ray& ray, float limit, int& info,
+                         unsigned& c_nodes, unsigned& c_tris) {
+    info = 0;
+    if (S.node_count == 0) return -1;
+    Trav T;
+    trav_begin(T, ray.o, ray.d, false, -1, limit);
+    TravStep st;
+    while (trav_choose(T, S, stack, spill, st)) {
+        TravData D;
+        trav_fetch(S, st, D);
+        trav_apply<COUNT>(T, S, st, D, c_nodes, c_tris);
+    }
+    const int h2 = T.overflow ? -2 : ((T.s0 >= 0 && T.s1 >= 0) ? T.s1 : -1);
+    info = T.overflow ? 2 : (h2 >= 0 ? 1 : 0);     // 0 one survivor (or none), 1 two survivors -> exact metric, 2 -> exact re-trace
+    return resolve_closest<COUNT>(S, stack2, ray, T.s0 >= 0 ? T.s0 : T.s1, h2, c_nodes, c_tris);
+}
+template <bool COUNT>
+ERD bool trav_run_shadow(const DevScene& S, uint2* stack, uint2* spill, int* stack2, const Ray& ray, int self_slot, float limit, int& info,
+                         unsigned& c_nodes, unsigned& c_tris) {
+    info = 0;
+    if (S.node_count == 0) return false;
+    Trav T;
+    trav_begin(T, ray.o, ray.d, true, self_slot, limit);
+    TravStep st;
+    int code = -1;
+    while (trav_choose(T, S, stack, spill, st)) {
+        TravData D;
+        trav_fetch(S, st, D);
+        if (trav_apply<COUNT>(T, S, st, D, c_nodes, c_tris)) { code = 1; break; }
+    }
+    if (code < 0) code = T.overflow ? 3 : (T.s0 >= 0 ? 2 : 0);
+    info = code;                                   // 0 / 1 decided by the t-intervals, 2 exact metric of <= 2 candidates, 3 exact re-trace
+    return resolve_shadow<COUNT>(S, stack2, ray, self_slot, limit, code, T.s0, T.s1, c_nodes, c_tris);
+}
+
 }  // namespace erd

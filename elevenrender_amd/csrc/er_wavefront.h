@@ -21,7 +21,7 @@ struct DevScene;
 // its state with dwordx4 accesses.
 struct WfState {
     float4* ray_o;     // closest-hit ray origin (xyz)
-    float4* ray_d;     // closest-hit ray direction (xyz)
+    float4* ray_d;     // closest-hit ray direction (xyz), w = brdfpdf of the last opaque bounce (ER_FLAG_MIS; < 0 none)
     int* hit;          // triangle slot of the closest hit, -1 = miss (written by trace)
     int* hit2;         // second surviving candidate (exact metric decides in shade), -1 none, -2 = re-trace exactly
     float4* light;     // xyz = accumulated radiance of the current path, w = bits(RNG state)
@@ -41,9 +41,13 @@ struct WfState {
     uint32_t* qs[2];   // shadow queues (slot)
     uint32_t* counts;  // WF_COUNTS words
     uint2* spill;      // per persistent trace wave: ER_BVH_MAX_DEPTH x 64 stack entries beyond the LDS levels
+    uint32_t slots;    // owned_tile_count * 64.  With ER_FLAG_POINT_LIGHTS the shadow records (sh_o, sh_d, c_vis, c_occ,
+                       // occluded, occ_a, occ_b) have 2 * slots entries: [slot] = the HDRI query, [slot + slots] = the
+                       // point-light query of the same bounce; shadow-queue entries are these indices
     uint32_t pool, pools;   // this state drives the owned tiles t with t % pools == pool (see er_api.cpp: slot pools)
 };
 
 void er_launch_wf_begin(const DevScene& S, const WfState& W, uint32_t n_samples, hipStream_t stream);
-void er_launch_wf_trace(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t blocks, hipStream_t stream);
+// ray_log (may be NULL): the launch stores the number of rays it found in its queues there (ER_FLAG_PROFILE)
+void er_launch_wf_trace(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t blocks, uint32_t* ray_log, hipStream_t stream);
 void er_launch_wf_shade(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t blocks, hipStream_t stream);

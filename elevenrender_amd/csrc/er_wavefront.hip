@@ -23,6 +23,7 @@
 #include "er_kernels.h"
 #include "er_wavefront.h"
 #include "er_trav.h"
+#include "er_shade.h"
 
 using namespace erd;
 
@@ -67,6 +68,7 @@ __device__ __forceinline__ void slot_pixel(const DevScene& S, uint32_t slot, uin
 
 // packed per-slot flags in reduc.w: bounce (bits 0-15) | pending shadow (bit 16)
 #define WF_PENDING 0x10000u
+#define WF_LPENDING 0x20000u   // ... | pending point-light shadow (bit 17)
 
 // ---- begin: first camera ray of every slot, queue 0 = all valid slots ----
 __global__ __launch_bounds__(64) void er_wf_begin(DevScene S, WfState W, uint32_t n_samples) {
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(64) void er_wf_begin(DevScene S, WfState W, uint32_
         float c1 = rng_next(rs), c2 = rng_next(rs), c3 = rng_next(rs), c4 = rng_next(rs), c5 = rng_next(rs);
         Ray ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
         W.ray_o[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
-        W.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f);
+        W.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, -1.0f);   // w: brdfpdf of the last opaque bounce (ER_FLAG_MIS)
         W.light[slot] = make_float4(0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, rs));
         W.reduc[slot] = make_float4(1.0f, 1.0f, 1.0f, __builtin_bit_cast(float, 0u));
         W.aov_n[slot] = make_float4(0, 0, 0, 0);
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(64) void er_wf_begin(DevScene S, WfState W, uint32_
 #define WF_TRACE_WAVES 4
 #endif
 template <bool COUNT>
-__global__ __launch_bounds__(64, WF_TRACE_WAVES) void er_wf_trace(DevScene S, WfState W, uint32_t parity, uint32_t refill_min) {
+__global__ __launch_bounds__(64, WF_TRACE_WAVES) void er_wf_trace(DevScene S, WfState W, uint32_t parity, uint32_t refill_min, uint32_t* ray_log) {
     __shared__ uint2 s_stack[WF_LDS_STACK * 64];
     const int lane = threadIdx.x;
     uint2* stack = s_stack + lane;
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(64, WF_TRACE_WAVES) void er_wf_trace(DevScene S, Wf
         W.counts[WF_NC + WF_PAR(parity ^ 1)] = 0;
         W.counts[WF_NS + WF_PAR(parity ^ 1)] = 0;
         W.counts[WF_TS] = 0;
+        if (ray_log) *ray_log = nC + nS;
     }
     const uint32_t total = nC + nS;
     const uint32_t* qc = W.q[parity];
@@ -237,12 +240,36 @@ __global__ __launch_bounds__(64, WF_TRACE_WAVES) void er_wf_trace(DevScene S, Wf
 #ifndef WF_SHADE_WAVES
 #define WF_SHADE_WAVES 4
 #endif
-template <bool COUNT>
+// the wavefront schedule's sink (er_shade.h): queries and AOVs go straight to the slot's records in HBM
+struct WfSink {
+    const WfState& W;
+    uint32_t slot;
+    ERD void hdri_query(const Ray& sr, int self_slot, float d_self, F3 c_vis, F3 c_occ) {
+        W.sh_o[slot] = make_float4(sr.o.x, sr.o.y, sr.o.z, __builtin_bit_cast(float, self_slot));
+        W.sh_d[slot] = make_float4(sr.d.x, sr.d.y, sr.d.z, d_self);
+        W.c_vis[slot] = make_float4(c_vis.x, c_vis.y, c_vis.z, 0.0f);
+        W.c_occ[slot] = make_float4(c_occ.x, c_occ.y, c_occ.z, 0.0f);
+    }
+    ERD void light_query(const Ray& lr, float limit, F3 l_vis, F3 l_occ) {
+        const uint32_t q = slot + W.slots;     // the point-light query of a slot lives in the second half of the records
+        W.sh_o[q] = make_float4(lr.o.x, lr.o.y, lr.o.z, __builtin_bit_cast(float, -1));
+        W.sh_d[q] = make_float4(lr.d.x, lr.d.y, lr.d.z, limit);
+        W.c_vis[q] = make_float4(l_vis.x, l_vis.y, l_vis.z, 0.0f);
+        W.c_occ[q] = make_float4(l_occ.x, l_occ.y, l_occ.z, 0.0f);
+    }
+    ERD void first_hit(F3 n, F3 t, F3 b) {
+        W.aov_n[slot] = make_float4(n.x, n.y, n.z, 0.0f);
+        W.aov_t[slot] = make_float4(t.x, t.y, t.z, 0.0f);
+        W.aov_b[slot] = make_float4(b.x, b.y, b.z, 0.0f);
+    }
+};
+
+template <bool COUNT, bool EXT>
 __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, WfState W, uint32_t parity) {
     __shared__ int s_stack[ER_STACK * 64];   // only for the rare exact re-trace of an overflowed ray
     // queue entries are staged per wave and appended WF_STAGE tickets at a time: the two queue-length words are
     // single addresses, and one address takes ~90 atomics/us whatever the number of waves
-    __shared__ uint32_t s_qc[WF_STAGE * 64], s_qs[WF_STAGE * 64];
+    __shared__ uint32_t s_qc[WF_STAGE * 64], s_qs[WF_STAGE * 64];   // (a ticket stages <= 64 closest and <= 128 shadow entries)
     unsigned n_qc = 0, n_qs = 0;             // staged entries (wave-uniform)
     const int lane = threadIdx.x;
     int* stack = s_stack + lane;
@@ -253,8 +280,6 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
     const uint32_t* qc = W.q[parity];
     uint32_t* qn = W.q[parity ^ 1];
     uint32_t* qsn = W.qs[parity ^ 1];
-    const size_t npx = (size_t)S.x_res * S.y_res;
-    const int hw = S.hdri_tex.width, hh = S.hdri_tex.height;
     unsigned c_paths = 0, c_bounce = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;
     // tickets (64 slots each) are taken several at a time: one atomic per chunk
     uint32_t tchunk = wC / (gridDim.x * 4u);
@@ -269,7 +294,7 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
             t_end = base + tchunk < wC ? base + tchunk : wC;
             if (base >= wC) break;
         }
-        if (n_qc > (WF_STAGE - 1) * 64 || n_qs > (WF_STAGE - 1) * 64) {   // no room for another ticket: append
+        if (n_qc > (WF_STAGE - 1) * 64 || n_qs > (WF_STAGE - 2) * 64) {   // no room for another ticket: append
             __syncthreads();
             queue_flush(&W.counts[WF_NC + WF_PAR(parity ^ 1)], qn, s_qc, n_qc);
             queue_flush(&W.counts[WF_NS + WF_PAR(parity ^ 1)], qsn, s_qs, n_qs);
@@ -279,7 +304,7 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
         uint32_t ticket = t_cur++;
         uint32_t item = ticket * 64 + lane;
         bool active = item < nC;
-        bool push_closest = false, push_shadow = false;
+        bool push_closest = false, push_shadow = false, push_light = false;
         uint32_t next_entry = 0, slot = 0;
         if (active) {
             uint32_t e = qc[item];
@@ -293,135 +318,52 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
             uint32_t rs = __builtin_bit_cast(uint32_t, L4.w);
             uint32_t packed = __builtin_bit_cast(uint32_t, R4.w);
             uint32_t bounce = packed & 0xFFFFu;
-            if (packed & WF_PENDING) {   // resolve the previous bounce's shadow query
-                int occ = W.occluded[slot];
-                if (occ >= 2) {          // the trace kernel could not decide from t-intervals: exact metric
-                    float4 so = W.sh_o[slot], sd = W.sh_d[slot];
-                    Ray sr;
-                    sr.o = f3(so.x, so.y, so.z);
-                    sr.d = f3(sd.x, sd.y, sd.z);
-                    if (occ == 3) {
-                        float dd;
-                        occ = trace<COUNT, true>(S, stack, sr, __builtin_bit_cast(int, so.w), sd.w, dd, c_nodes, c_tris) >= 0 ? 1 : 0;
-                    } else {
-                        int ca = W.occ_a[slot], cb = W.occ_b[slot];
-                        bool nearer = exact_distance(S, (uint32_t)ca, sr) < sd.w;
-                        if (cb >= 0) nearer = nearer || (exact_distance(S, (uint32_t)cb, sr) < sd.w);
-                        occ = nearer ? 1 : 0;
+            // resolve the previous bounce's shadow queries, in the order of the additions: HDRI term, then point light
+#pragma unroll
+            for (int kind = 0; kind < (EXT ? 2 : 1); kind++) {
+                if (packed & (kind ? WF_LPENDING : WF_PENDING)) {
+                    const uint32_t q = slot + (kind ? W.slots : 0u);     // light queries live in the second half
+                    int occ = W.occluded[q];
+                    if (occ >= 2) {          // the trace kernel could not decide from t-intervals: exact metric
+                        float4 so = W.sh_o[q], sd = W.sh_d[q];
+                        Ray sr;
+                        sr.o = f3(so.x, so.y, so.z);
+                        sr.d = f3(sd.x, sd.y, sd.z);
+                        occ = resolve_shadow<COUNT>(S, stack, sr, __builtin_bit_cast(int, so.w), sd.w, occ, W.occ_a[q], W.occ_b[q], c_nodes, c_tris) ? 1 : 0;
                     }
+                    float4 c = occ ? W.c_occ[q] : W.c_vis[q];
+                    light = light + f3(c.x, c.y, c.z);
                 }
-                float4 c = occ ? W.c_occ[slot] : W.c_vis[slot];
-                light = light + f3(c.x, c.y, c.z);
             }
-            bool pending = false;
+            bool pending = false, lpending = false;
             bool done = fin_only;
             Ray ray;
+            float prev_pdf = -1.0f;
             if (!fin_only) {
                 float4 o = W.ray_o[slot], d = W.ray_d[slot];
                 ray.o = f3(o.x, o.y, o.z);
                 ray.d = f3(d.x, d.y, d.z);
-                int hslot = W.hit[slot];
-                int h2 = W.hit2[slot];
-                if (h2 == -2) {          // more than two candidates inside one t-interval: exact scalar traversal
-                    float dd;
-                    hslot = trace<COUNT, false>(S, stack, ray, -1, __builtin_inff(), dd, c_nodes, c_tris);
-                } else if (h2 >= 0) {    // two candidates: the reference's strict '<' on the exact metric
-                    if (exact_distance(S, (uint32_t)h2, ray) < exact_distance(S, (uint32_t)hslot, ray)) hslot = h2;
-                }
+                if (EXT) prev_pdf = d.w;
+                const int hslot = resolve_closest<COUNT>(S, stack, ray, W.hit[slot], W.hit2[slot], c_nodes, c_tris);
                 c_bounce++;
-                if (hslot < 0) {
-                    float u, v;
-                    spherical_mapping(-1 * ray.d, u, v);
-                    light = light + reduction * tex_filtered(S, S.hdri_tex, u, v);
-                    if (COUNT) c_texels++;
-                    done = true;
-                } else {
-                    c_shaded++;
-                    HitFull hit;
-                    full_hit(S, (uint32_t)hslot, ray, hit);
-                    const ErMaterial& mat = S.materials[hit.material];
-                    HitData hd;
-                    generate_hit_data<COUNT>(S, mat, hit, hd, c_texels);
-                    int shader = mat.albedo_shader_id;
-                    if (shader != -1) {
-                        hd.albedo = f3s(0);
-                        if (shader >= 0 && shader < 4) hd.albedo = f3(1, 1, 0);
-                    }
-                    if (rng_next(rs) <= hd.opacity) {
-                        F3 wo = ray.d * -1.0f;
-                        F3 N = hd.normal;
-                        c_hdri++;
-                        int count = er_cdf_search(S.hdri_cdf, hw * hh, S.hdri_guide, S.hdri_buckets, rng_next(rs));   // == HDRI::binarySearch
-                        float tcx = (float)(count % hw), tcy = (float)(count / hw);
-                        float d1 = rng_next(rs), d2 = rng_next(rs), d3 = rng_next(rs);
-                        F3 wibrdf = DisneySample(hd, wo, N, d1, d2, d3);
-                        float nu = tcx / (float)hw, nv = tcy / (float)hh;
-                        float iu, iv;
-                        inverse_transform_uv(S.hdri_tex, nu, nv, iu, iv);
-                        F3 wihdri = normalized(reverse_spherical_mapping(iu, iv)) * -1.0f;
-                        F3 hdriValue = tex_uv(S, S.hdri_tex, iu, iv);
-                        if (COUNT) c_texels += 2;
-                        F3 evalh = DisneyEval(hd, wo, N, wihdri);
-                        float hdripdf = hdri_pdf(S, ermath::f2i(iu * hw), ermath::f2i(iv * hh));
-                        float absdot = __builtin_fabsf(dot(wihdri, N));
-                        F3 c_vis = reduction * (hd.emission + hdriValue * evalh * absdot / hdripdf);
-                        if (evalh.x != 0.0f || evalh.y != 0.0f || evalh.z != 0.0f) {
-                            // shadow query needed (see er_kernels.hip): occluded iff the closest hit is another triangle
-                            F3 c_occ = reduction * (hd.emission + f3s(0) * evalh * absdot / hdripdf);
-                            Ray sr = make_ray(hd.position + N * 0.001f, wihdri);
-                            F3 v0, v1, v2;
-                            float4 qa, qb, qc4;
-                            load_verts(S, (uint32_t)hslot, v0, v1, v2, qa, qb, qc4);
-                            float su, sv, st, d_self = __builtin_inff();
-                            if (tri_mt(v0, v1, v2, sr, su, sv, st)) d_self = candidate_distance(S, (uint32_t)hslot, v0, v1, v2, sr, su, sv, st);
-                            W.sh_o[slot] = make_float4(sr.o.x, sr.o.y, sr.o.z, __builtin_bit_cast(float, hslot));
-                            W.sh_d[slot] = make_float4(sr.d.x, sr.d.y, sr.d.z, d_self);
-                            W.c_vis[slot] = make_float4(c_vis.x, c_vis.y, c_vis.z, 0.0f);
-                            W.c_occ[slot] = make_float4(c_occ.x, c_occ.y, c_occ.z, 0.0f);
-                            pending = true;
-                        } else {
-                            light = light + c_vis;
-                        }
-                        float brdfpdf = DisneyPdf(hd, wo, N, wibrdf);
-                        reduction = reduction * (DisneyEval(hd, wo, N, wibrdf) * __builtin_fabsf(dot(wibrdf, N)) / brdfpdf);
-                        if (bounce == 0) {
-                            W.aov_n[slot] = make_float4(hd.normal.x, hd.normal.y, hd.normal.z, 0.0f);
-                            W.aov_t[slot] = make_float4(hd.tangent.x, hd.tangent.y, hd.tangent.z, 0.0f);
-                            W.aov_b[slot] = make_float4(hd.bitangent.x, hd.bitangent.y, hd.bitangent.z, 0.0f);
-                        }
-                        ray = make_ray(hit.position + wibrdf * 0.001f, wibrdf);
-                    } else {
-                        ray = make_ray(hit.position + ray.d * 0.001f, ray.d);
-                    }
-                    bounce++;
-                    if (bounce >= S.max_bounces) done = true;
-                }
+                BounceOut bo;
+                WfSink sink{W, slot};
+                bounce_step<COUNT, EXT>(S, ray, hslot, rs, light, reduction, bounce, prev_pdf, bo, sink, c_shaded, c_texels, c_hdri);
+                pending = bo.shadow;
+                lpending = EXT && bo.lshadow;
+                ray = bo.next;
+                done = bo.done;
             }
             bool alive = true;
-            if (done && pending) {
-                // the path is over but its last shadow query is in flight: come back once, without a ray
+            if (done && (pending || lpending)) {
+                // the path is over but its last shadow queries are in flight: come back once, without a ray
                 next_entry = slot | ER_WF_FINALIZE_ONLY;
                 push_closest = true;
             } else if (done) {
-                // src/kernel.cpp:597-645
-                light = f3(clampf(light.x, 0, 10), clampf(light.y, 0, 10), clampf(light.z, 0, 10));
-                uint32_t sa = S.samples[idx];
-                if (!(light.x != light.x) && !(light.y != light.y) && !(light.z != light.z)) {
-                    float k = ((float)sa) / ((float)(sa + 1));
-                    float inv = (float)(sa + 1);
-                    float4 an = W.aov_n[slot], at = W.aov_t[slot], ab = W.aov_b[slot];
-                    const F3 vals[4] = {light, f3(an.x, an.y, an.z), f3(at.x, at.y, at.z), f3(ab.x, ab.y, ab.z)};
-                    const int planes[4] = {ER_PASS_BEAUTY, ER_PASS_NORMAL, ER_PASS_TANGENT, ER_PASS_BITANGENT};
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        float4* pp = S.passes + (size_t)planes[q] * npx + idx;
-                        float4 p = *pp;
-                        if (sa > 0) { p.x *= k; p.y *= k; p.z *= k; }
-                        p.x += vals[q].x / inv; p.y += vals[q].y / inv; p.z += vals[q].z / inv;
-                        *pp = p;
-                    }
-                    S.samples[idx] = sa + 1;
-                }
+                float4 an = W.aov_n[slot], at = W.aov_t[slot], ab = W.aov_b[slot];
+                const uint32_t sa = S.samples[idx];
+                const uint32_t sa2 = accumulate_sample(S, idx, sa, light, f3(an.x, an.y, an.z), f3(at.x, at.y, at.z), f3(ab.x, ab.y, ab.z));
+                if (sa2 != sa) S.samples[idx] = sa2;
                 S.rng[idx] = rs;
                 c_paths++;
                 uint32_t left = W.left[slot] - 1;
@@ -432,6 +374,7 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
                     light = f3s(0);
                     reduction = f3s(1);
                     bounce = 0;
+                    prev_pdf = -1.0f;
                     W.aov_n[slot] = make_float4(0, 0, 0, 0);
                     W.aov_t[slot] = make_float4(0, 0, 0, 0);
                     W.aov_b[slot] = make_float4(0, 0, 0, 0);
@@ -445,22 +388,27 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
                 push_closest = true;
             }
             push_shadow = pending;
+            push_light = lpending;
             if (alive) {
                 if (!(next_entry & ER_WF_FINALIZE_ONLY)) {
                     W.ray_o[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
-                    W.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f);
+                    W.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, prev_pdf);
                 }
                 W.light[slot] = make_float4(light.x, light.y, light.z, __builtin_bit_cast(float, rs));
                 W.reduc[slot] = make_float4(reduction.x, reduction.y, reduction.z,
-                                            __builtin_bit_cast(float, bounce | (pending ? WF_PENDING : 0u)));
+                                            __builtin_bit_cast(float, bounce | (pending ? WF_PENDING : 0u) | (lpending ? WF_LPENDING : 0u)));
             }
         }
-        const unsigned long long mc = __ballot(push_closest), ms = __ballot(push_shadow);
+        const unsigned long long mc = __ballot(push_closest), ms = __ballot(push_shadow), ml = __ballot(push_light);
         const unsigned long long below = (1ull << lane) - 1ull;
         if (push_closest) s_qc[n_qc + __popcll(mc & below)] = next_entry;
         if (push_shadow) s_qs[n_qs + __popcll(ms & below)] = slot;
         n_qc += __popcll(mc);
         n_qs += __popcll(ms);
+        if (EXT && ml) {   // point-light queries (ER_FLAG_POINT_LIGHTS): entry = slot + slots, the second half of the shadow records
+            if (push_light) s_qs[n_qs + __popcll(ml & below)] = slot + W.slots;
+            n_qs += __popcll(ml);
+        }
     }
     __syncthreads();
     queue_flush(&W.counts[WF_NC + WF_PAR(parity ^ 1)], qn, s_qc, n_qc);
@@ -476,24 +424,34 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
     }
 }
 
+hipError_t er_probe_wavefront(const char** which) {
+    hipFuncAttributes a;
+    hipError_t e;
+    *which = "er_wf_trace";
+    if ((e = hipFuncGetAttributes(&a, (const void*)er_wf_trace<false>)) != hipSuccess) return e;
+    *which = "er_wf_shade";
+    return hipFuncGetAttributes(&a, (const void*)er_wf_shade<false, false>);
+}
+
 void er_launch_wf_begin(const DevScene& S, const WfState& W, uint32_t n_samples, hipStream_t stream) {
     if (S.owned_tile_count <= W.pool) return;
     (void)hipMemsetAsync(W.counts, 0, WF_COUNTS * sizeof(uint32_t), stream);
     const uint32_t tiles = (S.owned_tile_count - W.pool + W.pools - 1) / W.pools;
     hipLaunchKernelGGL(er_wf_begin, dim3(tiles), dim3(64), 0, stream, S, W, n_samples);
 }
-void er_launch_wf_trace(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t blocks, hipStream_t stream) {
+void er_launch_wf_trace(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t blocks, uint32_t* ray_log, hipStream_t stream) {
     static const uint32_t refill_min = [] {
         const char* e = getenv("ER_TRACE_REFILL_MIN");
         int v = e ? atoi(e) : WF_REFILL_MIN;
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     if (S.owned_tile_count == 0) return;
-    if (count) hipLaunchKernelGGL(er_wf_trace<true>, dim3(blocks), dim3(64), 0, stream, S, W, parity, refill_min);
-    else hipLaunchKernelGGL(er_wf_trace<false>, dim3(blocks), dim3(64), 0, stream, S, W, parity, refill_min);
+    if (count) hipLaunchKernelGGL(er_wf_trace<true>, dim3(blocks), dim3(64), 0, stream, S, W, parity, refill_min, ray_log);
+    else hipLaunchKernelGGL(er_wf_trace<false>, dim3(blocks), dim3(64), 0, stream, S, W, parity, refill_min, ray_log);
 }
 void er_launch_wf_shade(const DevScene& S, const WfState& W, uint32_t parity, bool count, uint32_t blocks, hipStream_t stream) {
     if (S.owned_tile_count == 0) return;
-    if (count) hipLaunchKernelGGL(er_wf_shade<true>, dim3(blocks), dim3(64), 0, stream, S, W, parity);
-    else hipLaunchKernelGGL(er_wf_shade<false>, dim3(blocks), dim3(64), 0, stream, S, W, parity);
+    const bool ext = er_ext_active(S);
+    auto k = count ? (ext ? er_wf_shade<true, true> : er_wf_shade<true, false>) : (ext ? er_wf_shade<false, true> : er_wf_shade<false, false>);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(64), 0, stream, S, W, parity);
 }

@@ -67,3 +67,54 @@ def gather_plane(dist, rank, world, my_compact, max_rows, unpack):
         for r in range(world):
             if r != 0:
                 unpack(r, gathered[r])
+
+
+def gather_all_planes_torch(dist, rm, rank, world, planes=(0, 1, 2, 3, 4)):
+    """All pass planes through torch.distributed (the test-harness path: gloo on the CPU tests / rehearsal; the
+    production combine is NativeComm below).  `rm` is a render.RenderingManager begun with this rank / world."""
+    import torch
+    rows = [rm.owned_count(r) for r in range(world)]
+    on_cuda = dist.get_backend() == "nccl"
+    for p in planes:
+        # torch.empty: er_pack_owned writes every row, and it runs on the library's own stream -- a torch.zeros fill
+        # on torch's stream could land after the pack and blank it (round-1 advice)
+        mine = torch.empty((rows[rank], 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        rm.pack_owned(p, mine.data_ptr())          # synchronises the library's stream before returning
+
+        def unpack(r, t, p=p):
+            t = t.contiguous().cuda()
+            torch.cuda.synchronize()
+            rm.unpack_owned(p, r, t.data_ptr())
+        gather_plane(dist, rank, world, mine if on_cuda else mine.cpu(), max(rows), unpack)
+
+
+class NativeComm:
+    """The library's own RCCL communicator (include/eleven_hip.h: er_comm_*, er_gather_pass).  Only the 128-byte
+    unique id travels through the host's channel -- here a torch.distributed broadcast; the pixel data moves from the
+    C++ side with ncclSend / ncclRecv over xGMI."""
+
+    def __init__(self, dist, rank, world, device):
+        import ctypes as C
+        import torch
+        from . import abi
+        self.lib = abi.load()
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            abi.check(self.lib.er_comm_unique_id(ident))
+        t = torch.tensor(list(ident), dtype=torch.uint8)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.broadcast(t, src=0)
+        ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        self.handle = C.c_void_p()
+        abi.check(self.lib.er_comm_create(ident, rank, world, device, C.byref(self.handle)))
+
+    def gather_pass(self, rm, pass_id, root=0):
+        from . import abi
+        abi.check(self.lib.er_gather_pass(rm.handle, pass_id, self.handle, root))
+
+    def close(self):
+        if self.handle:
+            self.lib.er_comm_destroy(self.handle)
+            self.handle = None

@@ -51,6 +51,14 @@ def list_devices():
     return out
 
 
+def measure_hbm_peak(device=0, nbytes=0, iters=0):
+    """er_measure_hbm_peak: (copy GB/s counting read + write, read-only GB/s) of a streaming kernel over `nbytes`."""
+    lib = abi.load()
+    a, b = C.c_float(), C.c_float()
+    abi.check(lib.er_measure_hbm_peak(device, nbytes, iters, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 class RenderingManager:
     """start_rendering(scene) / render(n) / get_pass(name) / get_render_info() over the C ABI."""
 
@@ -144,6 +152,31 @@ class RenderingManager:
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
         abi.check(self.lib.er_debug_closest_hit(self.handle, fp(o), fp(d), n, tri.ctypes.data_as(C.POINTER(C.c_int32)), fp(pos), fp(dist)))
         return tri, pos, dist
+
+    def debug_trace_rays(self, origins, dirs, self_slots=None, limits=None):
+        """include/eleven_hip_debug.h: rays through the PRODUCTION traversal (er_trav.h + resolve_closest/resolve_shadow).
+        Closest queries return (tri, slot, pos, dist, info); shadow queries (self_slots given) return (occluded, info)."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = len(o)
+        tri, slot, info = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.int32)
+        pos, dist = np.empty((n, 3), np.float32), np.empty(n, np.float32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+        if self_slots is None:
+            abi.check(self.lib.er_debug_trace_rays(self.handle, fp(o), fp(d), n, None, None, ip(tri), ip(slot), fp(pos), fp(dist), ip(info)))
+            return tri, slot, pos, dist, info
+        ss = np.ascontiguousarray(self_slots, np.int32)
+        lim = np.ascontiguousarray(limits, np.float32)
+        abi.check(self.lib.er_debug_trace_rays(self.handle, fp(o), fp(d), n, ip(ss), fp(lim), ip(tri), ip(slot), fp(pos), fp(dist), ip(info)))
+        return tri.astype(bool), info
+
+    def debug_trace_pixel(self, idx, max_recs=64):
+        """include/eleven_hip_debug.h: one more sample of pixel idx, one ErTraceRec per bounce-loop iteration."""
+        recs = (abi.ErTraceRec * max_recs)()
+        n = C.c_int()
+        abi.check(self.lib.er_debug_trace_pixel(self.handle, idx, recs, max_recs, C.byref(n)))
+        return [recs[i] for i in range(n.value)]
 
     def owned_count(self, rank):
         v = C.c_uint64()

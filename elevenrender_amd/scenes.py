@@ -132,11 +132,22 @@ def value_noise_texture(size, seed, channels=3):
     return (np.clip(a, 0, 1).astype(np.float32), size, size, channels, 0)
 
 
+def point_lights(n=256, seed=12345, lo=(-1.0, -1.0, 2.0), hi=(1.0, 1.0, 4.0)):
+    """`n` point lights at U([-1,1]^2 x [2,4]) with radiance U(0.5,2)^3 (reference PointLight,
+    src/PointLight.h:4-16).  They only take effect with ER_FLAG_POINT_LIGHTS (a build-defined extension, a15)."""
+    r = Rand(seed, 7)
+    u = r.u01(n, 3)
+    pos = (np.asarray(lo, np.float32) + (np.asarray(hi, np.float32) - np.asarray(lo, np.float32)) * u).astype(np.float32)
+    rad = r.uniform(0.5, 2.0, n, 3)
+    return [abi.ErPointLight(abi.ErVec3(*map(float, pos[i])), abi.ErVec3(*map(float, rad[i]))) for i in range(n)]
+
+
 def torture(n_tris=1_000_000, x_res=1920, y_res=1080, seed=12345, n_materials=64, tex_size=256,
-            hdri_size=(2048, 1024), smooth=False):
+            hdri_size=(2048, 1024), smooth=False, n_lights=256):
     """C5: C2 geometry, `n_materials` textured materials (albedo + roughness + metallic noise textures),
-    clearcoat/anisotropic/sheen varied per material.  Point lights of the spec are the extension path
-     and are not part of this descriptor's default."""
+    clearcoat/anisotropic/sheen varied per material, `n_lights` point lights (evaluated only with
+    ER_FLAG_POINT_LIGHTS: the extension path of SURVEY 8 a15; without the flag they are ignored like the
+    reference ignores them)."""
     sc = soup(n_tris, x_res, y_res, seed, hdri_size)
     sc.material_id = (np.arange(n_tris, dtype=np.int64) % n_materials).astype(np.int32)
     textures, materials = [], []
@@ -149,6 +160,7 @@ def torture(n_tris=1_000_000, x_res=1920, y_res=1080, seed=12345, n_materials=64
                                               clearcoat=(m % 4) / 3.0, anisotropic=(m % 5) / 5.0, sheen=(m % 3) / 2.0))
     sc.textures = [(abi._f32(d), w, h, ch, flt) for (d, w, h, ch, flt) in textures]
     sc.materials = materials
+    sc.point_lights = point_lights(n_lights, seed)
     if smooth:
         r = Rand(seed, 3)
         jitter = r.uniform(-0.35, 0.35, n_tris, 3, 3)

@@ -110,7 +110,10 @@ typedef struct ErSceneDesc {
     uint32_t x_res, y_res;
 } ErSceneDesc;
 
-#define ER_FLAG_POINT_LIGHTS 1u   /* extension, default off = reference behaviour */
+#define ER_FLAG_POINT_LIGHTS 1u   /* extension, default off = reference behaviour: one point-light sample per opaque
+                                     bounce after the author's sketch src/kernel.cpp:269-301 (rules: csrc/er_shade.h) */
+#define ER_FLAG_MIS          128u /* extension, default off = reference behaviour (NEE and BRDF-sampled environment both
+                                     counted in full, src/kernel.cpp:571-577): balance-heuristic weights per direction */
 #define ER_FLAG_COUNTERS     2u   /* count node visits / triangle tests (slower kernel variant) */
 /* Schedule selection (every schedule computes bit-identical results).  Default: automatic -- the wavefront schedule
  * when this rank owns many pixels (> 1.2M), the lane-asynchronous fused schedule otherwise (few pixels per GPU make
@@ -203,20 +206,47 @@ int er_owned_count(ErScene* scene, uint32_t rank, uint64_t* out);
 int er_pack_owned(ErScene* scene, int pass, void* dev_dst);
 int er_unpack_owned(ErScene* scene, int pass, uint32_t src_rank, const void* dev_src);
 
+/* The combine itself, from the C++ side (north_star: "RCCL reduce over xGMI only for the final framebuffer accumulate";
+ * reference hook: RenderingManager::get_pass, src/Managers.cpp:287-302).  One process per GPU:
+ *   rank 0: er_comm_unique_id(id) -> the host hands the 128 bytes to the other ranks through any channel it has
+ *           (the reference's host would use its TCP session; bench.py uses torch.distributed's broadcast)
+ *   all:    er_comm_create(id, rank, world, device, &comm)        -- ncclCommInitRank; RCCL is dlopen'ed at this point
+ *   all:    er_gather_pass(scene, pass, comm, root)               -- every rank packs the pixels it owns; the non-root
+ *           ranks ncclSend, the root ncclRecv's inside ONE group (xGMI is point to point: the seven links carry the
+ *           seven buffers side by side) and scatters them into its full plane.  One call per read-back, none per sample.
+ *   all:    er_comm_destroy(comm)
+ * The scene must have been begun with the communicator's rank / world. */
+typedef struct ErComm ErComm;
+#define ER_COMM_ID_BYTES 128
+int er_comm_unique_id(uint8_t id[ER_COMM_ID_BYTES]);
+int er_comm_create(const uint8_t id[ER_COMM_ID_BYTES], uint32_t rank, uint32_t world, int device, ErComm** out);
+void er_comm_destroy(ErComm* comm);
+int er_gather_pass(ErScene* scene, int pass, ErComm* comm, uint32_t root);
+
 int er_get_counters(ErScene* scene, ErCounters* out);
 
 /* Per-kernel device time of the launches enqueued since the previous er_wait, measured with HIP events on
  * the library's stream (needs ER_FLAG_PROFILE; valid after er_wait). */
 typedef struct ErProfile {
-    float trace_ms, shade_ms;          /* summed over launches */
-    uint32_t trace_launches, shade_launches;
+    float trace_ms, shade_ms;          /* summed over the launches that had rays to trace */
+    uint32_t trace_launches, shade_launches;   /* ... and their number */
     uint32_t schedule;                 /* ER_FLAG_WAVEFRONT / ER_FLAG_FUSED / ER_FLAG_MEGAKERNEL actually in use; for the
                                           two single-kernel schedules trace_ms is that kernel's time and shade_ms is 0 */
     uint32_t concurrency;              /* wavefront schedule: number of slot pools whose launches run side by side on
                                           their own streams (their durations overlap, so trace_ms + shade_ms exceeds the
                                           elapsed time by up to this factor); 1 otherwise */
+    uint32_t empty_launches;           /* wavefront schedule: trace + shade pairs that found empty queues (the host loop always
+                                          enqueues n * (max_bounces + 1) iterations), and their summed duration */
+    float empty_ms;
+    uint64_t rays_logged;              /* wavefront schedule: rays the counted trace launches found in their queues */
 } ErProfile;
 int er_get_profile(ErScene* scene, ErProfile* out);
+
+/* Measured HBM bandwidth of `device`, for the roofline's denominator ("the denominator used is the
+ * measured peak from a device-to-device copy / triad kernel run in the same job"): a streaming copy and a streaming
+ * read over `bytes` of device memory (0 -> 2 GiB, several times the 256 MB Infinity Cache), best of `iters` (0 -> 5)
+ * timed with HIP events.  copy counts bytes read + bytes written. */
+int er_measure_hbm_peak(int device, uint64_t bytes, uint32_t iters, float* copy_GBps, float* read_GBps);
 
 /* Description of the built acceleration structure, for roofline accounting. */
 typedef struct ErAccelInfo {

@@ -34,6 +34,51 @@ int er_debug_cdf_search(const float* cdf, int length, const float* values, int32
 struct ErScene;
 int er_debug_closest_hit(struct ErScene* scene, const float* origins, const float* dirs, uint32_t n, int32_t* tri_ids, float* positions, float* distances);
 
+/* The same query through the PRODUCTION traversal -- the 8-wide interval traversal of er_wf_trace / er_fused_kernel
+ * (csrc/er_trav.h: trav_choose / trav_fetch / trav_apply) followed by resolve_closest / resolve_shadow -- for `n`
+ * arbitrary rays (directions taken as given).
+ *   self_slots == NULL: closest-hit queries.  tri_ids = original triangle id (-1 miss), slots = the library's internal
+ *     triangle handle (feed it back as self_slots), positions = Hit.position, distances = |Hit.position - origin|
+ *     (inf on a miss), info = 0 one surviving candidate, 1 two survivors decided by the exact metric, 2 more than two:
+ *     exact re-trace.
+ *   self_slots != NULL: shadow queries, the reference's "occluded iff the closest hit is a triangle other than the one
+ *     the ray leaves" (src/kernel.cpp:555-562) in the form the kernels use: occluded iff some triangle other than
+ *     self_slots[i] (-1: none is exempt) is hit nearer than limits[i].  tri_ids = 1 occluded / 0 not; info = 0 / 1
+ *     decided by the t-intervals, 2 exact metric of the candidates, 3 exact re-trace. */
+int er_debug_trace_rays(struct ErScene* scene, const float* origins, const float* dirs, uint32_t n, const int32_t* self_slots,
+                        const float* limits, int32_t* tri_ids, int32_t* slots, float* positions, float* distances, int32_t* info);
+
+/* One record per executed bounce-loop iteration (reference src/kernel.cpp:508-592); same layout as the oracle's
+ * OracleTraceRec (oracle/er_oracle.h). */
+typedef struct ErTraceRec {
+    int32_t bounce;
+    int32_t tri;            /* ORIGINAL triangle id of the closest hit, -1 = miss */
+    int32_t shadow_tri;     /* original id of the HDRI shadow ray's closest hit, -1 = none / not traced */
+    int32_t opaque;         /* 1 if the opacity test passed */
+    float position[3];      /* Hit.position */
+    float wi[3];            /* next ray direction */
+    float light[3];         /* accumulated radiance after this iteration */
+    float reduction[3];     /* throughput after this iteration */
+    int32_t shadow_occ;     /* HDRI shadow query: 1 occluded, 0 visible, -1 not traced */
+    int32_t light_occ;      /* point-light query (ER_FLAG_POINT_LIGHTS): 1 occluded, 0 visible, -1 none */
+} ErTraceRec;
+
+/* Runs ONE more sample of pixel idx -- bounce_step (csrc/er_shade.h) over the production traversal, every query traced
+ * at once -- and records up to max_recs iterations.  The pixel's planes, sample count and RNG advance exactly as by
+ * er_render_samples(scene, 1) restricted to that pixel.  *count = records written. */
+int er_debug_trace_pixel(struct ErScene* scene, uint32_t idx, ErTraceRec* recs, int max_recs, int* count);
+
+/* Loopback transport for er_gather_pass: `world` communicators that live in ONE process and move the packed buffers
+ * through device-to-device copies, so that pack -> exchange -> unpack can be driven on a one-GPU box without RCCL (which
+ * refuses two ranks on one GPU).  out[world].  Call er_gather_pass for the non-root ranks first, then for the root. */
+struct ErComm;
+int er_debug_comm_create_local(uint32_t world, struct ErComm** out);
+
+/* Test hook for the out-of-memory path of the boundary: while `bytes` is non-zero, any single large host allocation the
+ * library announces (scene copy in er_scene_create, build staging in er_render_begin) larger than `bytes` fails as
+ * std::bad_alloc would, which the entry point must turn into ER_ERR_OOM (no exception crosses the C ABI).  0 = off. */
+void er_debug_set_host_alloc_limit(uint64_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -579,6 +579,8 @@ struct Oracle {
     ErCamera cam;
     uint32_t x_res = 0, y_res = 0;
     std::vector<Tri> tris;
+    std::vector<ErPointLight> lights;
+    uint32_t flags = 0;
     std::vector<ErMaterial> materials;
     std::vector<Tex> textures;
     Hdri hdri;
@@ -741,16 +743,25 @@ struct Oracle {
         calculateCameraRay(m, x, y, x_res, y_res, cam, ray, c1, c2, c3, c4, c5);
 
         V3 light(0.0f), normal(0.0f), tangent(0.0f), bitangent(0.0f), reduction(1.0f);
+        // the two build-defined extensions (rules: elevenrender_amd/csrc/er_shade.h; off = the reference)
+        const bool mis = (flags & ER_FLAG_MIS) != 0;
+        const bool use_lights = (flags & ER_FLAG_POINT_LIGHTS) != 0 && !lights.empty();
+        float prev_pdf = -1.0f;     // ER_FLAG_MIS: brdfpdf of the last opaque bounce
         for (int i = 0; i < max_bounces; i++) {
             c.bounce_samples++;
             HitData hd;
             Hit nearestHit = throwRay(ray, c);
             OracleTraceRec* rec = (recs && *nrec < max_recs) ? &recs[(*nrec)++] : nullptr;
-            if (rec) { memset(rec, 0, sizeof(*rec)); rec->bounce = i; rec->tri = nearestHit.valid ? nearestHit.tri : -1; rec->shadow_tri = -1; }
+            if (rec) { memset(rec, 0, sizeof(*rec)); rec->bounce = i; rec->tri = nearestHit.valid ? nearestHit.tri : -1; rec->shadow_tri = -1; rec->shadow_occ = -1; rec->light_occ = -1; }
             if (!nearestHit.valid) {
                 float u, v;
                 sphericalMapping(m, V3(), -1 * ray.direction, 1, u, v);
-                light = light + reduction * texFiltered(hdri.texture, u, v, &c.texel_fetches);
+                V3 env = texFiltered(hdri.texture, u, v, &c.texel_fetches);
+                if (mis && prev_pdf >= 0.0f) {   // balance heuristic for the BRDF-sampled direction that left the scene
+                    float p_h = hdriPdf(m, hdri, ermath::f2i(u * hdri.texture.width), ermath::f2i(v * hdri.texture.height), &c.texel_fetches);
+                    env = env * (1.0f / (1.0f + p_h / prev_pdf));
+                }
+                light = light + reduction * env;
                 if (rec) { rec->light[0] = light.x; rec->light[1] = light.y; rec->light[2] = light.z;
                            rec->reduction[0] = reduction.x; rec->reduction[1] = reduction.y; rec->reduction[2] = reduction.z; }
                 break;
@@ -768,6 +779,8 @@ struct Oracle {
                 c.hdri_samples++;
                 V3 textCoordinate = hdriSample(hdri, rnd.next());
                 float d1 = rnd.next(), d2 = rnd.next(), d3 = rnd.next();
+                float rl = 0.0f;
+                if (use_lights) rl = rnd.next();     // the light pick: one extra draw, right after DisneySample's three
                 V3 wibrdf = DisneySample(m, hd, wo, hd.normal, d1, d2, d3);
                 float nu = textCoordinate.x / (float)hdri.texture.width;
                 float nv = textCoordinate.y / (float)hdri.texture.height;
@@ -780,12 +793,39 @@ struct Oracle {
                 if (shadowHit.valid && shadowHit.triIdx != hd.triIdx) hdriValue = V3();
                 float hdripdf = hdriPdf(m, hdri, ermath::f2i(iu * hdri.texture.width), ermath::f2i(iv * hdri.texture.height), &c.texel_fetches);
                 V3 hdriInt = hdriValue * DisneyEval(m, hd, wo, hd.normal, wihdri) * std::fabs(dot(wihdri, hd.normal)) / hdripdf;
+                if (mis) hdriInt = hdriInt * (1.0f / (1.0f + DisneyPdf(m, hd, wo, hd.normal, wihdri) / hdripdf));   // balance heuristic, NEE direction
                 float brdfpdf = DisneyPdf(m, hd, wo, hd.normal, wibrdf);
                 light = light + reduction * (hd.emission + hdriInt);
+                if (use_lights) {
+                    // the author's sketch pointLight(), kernel.cpp:269-301
+                    int count = (int)lights.size();
+                    int k = ermath::f2i((float)count * rl);                       // :280
+                    if (k > count - 1) k = count - 1;                             // rnd.next() can return exactly 1.0
+                    const ErPointLight& L = lights[k];
+                    V3 lpos(L.position.x, L.position.y, L.position.z);
+                    V3 point = hd.position;
+                    V3 newDir = normalized(lpos - point);                         // :282
+                    float dist = length(lpos - point);                            // :284
+                    Ray shadowRay2(point + newDir * 0.001f, newDir);              // :287
+                    V3 pointLightValue = V3(L.radiance.x, L.radiance.y, L.radiance.z) / (dist * dist);   // :295
+                    V3 brdfDisney = DisneyEval(m, hd, wo, hd.normal, newDir);     // :297
+                    float lpdf = ((float)count) / (2.0f * PIF);                   // :275
+                    if (brdfDisney.x != 0.0f || brdfDisney.y != 0.0f || brdfDisney.z != 0.0f) {   // below the horizon: skipped
+                        V3 pl = pointLightValue * brdfDisney * std::fabs(dot(newDir, hd.normal)) / lpdf;   // :299-300
+                        Hit lh = throwRay(shadowRay2, c);                         // :288
+                        // :289-291, both distances from the shadow ray's origin
+                        const bool locc = lh.valid && length(lh.position - shadowRay2.origin) < length(lpos - shadowRay2.origin);
+                        if (locc) pl = V3();
+                        if (rec) rec->light_occ = locc ? 1 : 0;
+                        light = light + reduction * pl;
+                    }
+                }
                 reduction = reduction * (DisneyEval(m, hd, wo, hd.normal, wibrdf) * std::fabs(dot(wibrdf, hd.normal)) / brdfpdf);
+                if (mis) prev_pdf = brdfpdf;
                 if (i == 0) { normal = hd.normal; tangent = hd.tangent; bitangent = hd.bitangent; }
                 ray = Ray(nearestHit.position + wibrdf * 0.001f, wibrdf);
-                if (rec) { rec->opaque = 1; rec->shadow_tri = shadowHit.valid ? shadowHit.tri : -1; }
+                if (rec) { rec->opaque = 1; rec->shadow_tri = shadowHit.valid ? shadowHit.tri : -1;
+                           rec->shadow_occ = (shadowHit.valid && shadowHit.triIdx != hd.triIdx) ? 1 : 0; }
             } else {
                 ray = Ray(nearestHit.position + ray.direction * 0.001f, ray.direction);
             }
@@ -856,6 +896,8 @@ Oracle* oracle_create(const ErSceneDesc* d, const OracleOpts* opts) {
     o->max_bounces = (opts && opts->max_bounces > 0) ? opts->max_bounces : 5;
     o->traversal = opts ? opts->traversal : 0;
     o->threads = (opts && opts->threads > 0) ? opts->threads : 1;
+    o->flags = opts ? opts->flags : 0;
+    if (d->point_light_count && d->point_lights) o->lights.assign(d->point_lights, d->point_lights + d->point_light_count);
     o->cam = d->camera;
     o->x_res = d->x_res; o->y_res = d->y_res;
     o->tris.resize(d->tri_count);

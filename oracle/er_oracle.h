@@ -24,6 +24,8 @@ typedef struct OracleOpts {
     int32_t max_bounces;  /* 0 -> 5 (src/kernel.cpp:508) */
     int32_t traversal;    /* 0 = reference BVH (fixed depth 18, src/BVH.cpp), 1 = brute force over all tris */
     int32_t threads;      /* worker threads over pixel rows; <=0 -> 1 */
+    uint32_t flags;       /* ER_FLAG_POINT_LIGHTS | ER_FLAG_MIS: the two build-defined extensions, mirrored operation for
+                             operation from elevenrender_amd/csrc/er_shade.h (the reference defines no result for either) */
 } OracleOpts;
 
 typedef struct OracleCounters {
@@ -42,6 +44,8 @@ typedef struct OracleTraceRec {
     float wi[3];            /* next ray direction */
     float light[3];
     float reduction[3];
+    int32_t shadow_occ;     /* HDRI shadow query: 1 if shadowHit.valid && shadowHit.triIdx != hitdata.triIdx, 0 if not, -1 not traced */
+    int32_t light_occ;      /* point-light query (extension): 1 occluded, 0 visible, -1 none */
 } OracleTraceRec;
 
 typedef struct Oracle Oracle;

@@ -18,7 +18,8 @@ LIB_PATH = os.path.join(_HERE, "liberoracle.so")
 
 
 class OracleOpts(C.Structure):
-    _fields_ = [("math_mode", C.c_int32), ("max_bounces", C.c_int32), ("traversal", C.c_int32), ("threads", C.c_int32)]
+    _fields_ = [("math_mode", C.c_int32), ("max_bounces", C.c_int32), ("traversal", C.c_int32), ("threads", C.c_int32),
+                ("flags", C.c_uint32)]
 
 
 class OracleCounters(C.Structure):
@@ -28,7 +29,8 @@ class OracleCounters(C.Structure):
 
 class OracleTraceRec(C.Structure):
     _fields_ = [("bounce", C.c_int32), ("tri", C.c_int32), ("shadow_tri", C.c_int32), ("opaque", C.c_int32),
-                ("position", C.c_float * 3), ("wi", C.c_float * 3), ("light", C.c_float * 3), ("reduction", C.c_float * 3)]
+                ("position", C.c_float * 3), ("wi", C.c_float * 3), ("light", C.c_float * 3), ("reduction", C.c_float * 3),
+                ("shadow_occ", C.c_int32), ("light_occ", C.c_int32)]
 
 
 MATH_LIBM, MATH_ER = 0, 1
@@ -39,8 +41,8 @@ _FP = C.POINTER(C.c_float)
 
 
 def build(force=False):
-    if force or not os.path.exists(LIB_PATH):
-        subprocess.check_call(["make", "-C", _HERE, "liberoracle.so"] + (["-B"] if force else []))
+    # always through make: a no-op when up to date, and a stale .so (older struct layouts) never gets loaded
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liberoracle.so"] + (["-B"] if force else []))
 
 
 def lib():
@@ -97,10 +99,10 @@ def fp(a):
 class Oracle:
     """One oracle render state for a abi.SceneData."""
 
-    def __init__(self, scene, math_mode=MATH_ER, max_bounces=5, traversal=TRAV_REFERENCE_BVH, threads=1):
+    def __init__(self, scene, math_mode=MATH_ER, max_bounces=5, traversal=TRAV_REFERENCE_BVH, threads=1, flags=0):
         self.scene = scene
         self.L = lib()
-        opts = OracleOpts(math_mode, max_bounces, traversal, threads)
+        opts = OracleOpts(math_mode, max_bounces, traversal, threads, flags & (abi.FLAG_POINT_LIGHTS | abi.FLAG_MIS))
         self.h = self.L.oracle_create(C.byref(scene.desc()), C.byref(opts))
         self.npx = scene.x_res * scene.y_res
 

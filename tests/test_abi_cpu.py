@@ -138,3 +138,59 @@ def test_bvh_builder_threaded_equals_serial():
     a, b = bvh_check(v, nn, threads=1), bvh_check(v, nn, threads=8)
     assert (a.node_count, a.leaf_count, a.max_depth) == (b.node_count, b.leaf_count, b.max_depth)
     assert abs(a.sah_cost - b.sah_cost) < 1e-9 * max(1.0, a.sah_cost)
+
+
+def test_out_of_memory_comes_back_as_a_status_code_not_an_exception():
+    """The header promises "never throws": a std::bad_alloc inside an entry point must surface as ER_ERR_OOM.  The
+    allocator limit of include/eleven_hip_debug.h makes the scene copy of a valid, small description fail."""
+    lib = abi.load()
+    lib.er_debug_set_host_alloc_limit.argtypes = [C.c_uint64]
+    lib.er_debug_set_host_alloc_limit.restype = None
+    sc = scenes.soup(2000, 32, 24, seed=2, hdri_size=(64, 32))
+    h = C.c_void_p()
+    lib.er_debug_set_host_alloc_limit(1024)
+    try:
+        rc = lib.er_scene_create(C.byref(sc.desc()), C.byref(h))
+        assert rc == abi.ER_ERR_OOM, rc
+        assert b"out of host memory" in lib.er_last_error()
+        assert not h.value
+    finally:
+        lib.er_debug_set_host_alloc_limit(0)
+    assert lib.er_scene_create(C.byref(sc.desc()), C.byref(h)) == abi.ER_OK      # and the library is still usable
+    lib.er_scene_destroy(h)
+
+
+def test_shared_library_carries_gfx950_code_objects_only():
+    """Round 1 recorded a host crash inside the HIP runtime from a build of the .so that held no code object the
+    device could run ("No compatible code objects found for gfx950:sramecc+:xnack-").  er_render_begin now probes the
+    kernels (hipFuncGetAttributes) and returns ER_ERR_HIP; this test catches such a build before it travels: every
+    clang offload bundle in the library must hold exactly one device entry, for plain gfx950 (no xnack+/sramecc-
+    feature suffix, which the pool's xnack- devices refuse)."""
+    blob = open(abi.LIB_PATH, "rb").read()
+    bundles = blob.count(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert bundles >= 4, bundles            # er_kernels, er_wavefront, er_fused, er_gpu_build
+    entries = re.findall(rb"hip[v0-9]*-amdgcn-amd-amdhsa-[-A-Za-z0-9_:+]*", blob)
+    assert len(entries) >= bundles
+    for e in entries:
+        assert e.endswith(b"--gfx950"), e
+
+
+def test_collective_entry_points_validate_without_a_gpu():
+    lib = abi.load()
+    assert lib.er_gather_pass(None, 0, None, 0) == abi.ER_ERR_INVALID_ARG
+    comms = (C.c_void_p * 2)()
+    assert lib.er_debug_comm_create_local(2, comms) == abi.ER_OK      # host objects only
+    sc = scenes.cornell(16, 16)
+    h = C.c_void_p()
+    assert lib.er_scene_create(C.byref(sc.desc()), C.byref(h)) == abi.ER_OK
+    assert lib.er_gather_pass(h, 0, comms[0], 0) == abi.ER_ERR_STATE   # not begun
+    assert lib.er_gather_pass(h, 9, comms[0], 0) == abi.ER_ERR_INVALID_ARG
+    lib.er_scene_destroy(h)
+    for c in comms:
+        lib.er_comm_destroy(c)
+    lib.er_comm_destroy(None)
+    ident = (C.c_uint8 * 128)()
+    comm = C.c_void_p()
+    if lib.er_device_count() == 0:       # a communicator needs a device; the failure is a status code with a text
+        rc = lib.er_comm_create(ident, 0, 1, 0, C.byref(comm))
+        assert rc in (abi.ER_ERR_NO_DEVICE, abi.ER_ERR_HIP) and lib.er_last_error()

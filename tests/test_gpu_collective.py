@@ -1,0 +1,70 @@
+"""The framebuffer combine from the C++ side (include/eleven_hip.h: er_comm_*, er_gather_pass; csrc/er_collective.cpp).
+
+A one-GPU box cannot run RCCL with more than one rank (RCCL refuses two ranks on one device), so:
+  * the pack -> exchange -> unpack logic of er_gather_pass is driven for 3 ranks in ONE process over the loopback
+    transport of include/eleven_hip_debug.h -- the same code path, only the wire differs;
+  * the RCCL transport itself (dlopen, ncclGetUniqueId, ncclCommInitRank, destroy) is exercised with a communicator of
+    size 1.  The N-GPU run is bench.py --gpus N, which the driver launches on a whole node.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from elevenrender_amd import abi, render, scenes
+from test_gpu_parity import gpu_render
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("sched", [0, abi.FLAG_WAVEFRONT])
+def test_gather_pass_over_the_loopback_transport_reassembles_the_frame(sched):
+    lib = abi.load()
+    sc = scenes.soup(5000, 100, 76, seed=9, hdri_size=(64, 32))     # 100x76: partial tiles on both edges
+    full = gpu_render(sc, 5, max_bounces=8, flags=sched)
+    world, root = 3, 1                                              # a root that is not rank 0
+    comms = (C.c_void_p * world)()
+    abi.check(lib.er_debug_comm_create_local(world, comms))
+    rms = []
+    for r in range(world):
+        rm = render.RenderingManager(render.RenderParameters(max_bounces=8, rank=r, world=world, flags=sched))
+        rm.start_rendering(sc)
+        rm.render(5, blocking=False)            # no wait: the gather is ordered after the samples on the scene's stream
+        rms.append(rm)
+    for p in range(abi.PASS_COUNT):
+        for r in [x for x in range(world) if x != root] + [root]:
+            abi.check(lib.er_gather_pass(rms[r].handle, p, comms[r], root))
+    for name, p in abi.PASS_NAMES.items():
+        got = rms[root].get_pass(name)
+        assert (got.view(np.uint32) == full[name].view(np.uint32)).all(), name
+    # a non-root rank still holds only its own pixels
+    other = rms[0].get_pass("beauty")
+    assert (other.view(np.uint32) != full["beauty"].view(np.uint32)).any()
+    # the root before its peers have sent: a state error, not a hang
+    assert lib.er_gather_pass(rms[root].handle, 0, comms[root], root) == abi.ER_ERR_STATE
+    assert b"has not sent yet" in lib.er_last_error()
+    # rank / world of scene and communicator must match
+    assert lib.er_gather_pass(rms[0].handle, 0, comms[2], root) == abi.ER_ERR_INVALID_ARG
+    for rm in rms:
+        rm.close()
+    for c in comms:
+        lib.er_comm_destroy(c)
+
+
+def test_rccl_transport_initialises_and_a_one_rank_gather_is_a_no_op():
+    lib = abi.load()
+    ident = (C.c_uint8 * 128)()
+    abi.check(lib.er_comm_unique_id(ident))
+    assert any(ident)                            # RCCL filled it in
+    comm = C.c_void_p()
+    abi.check(lib.er_comm_create(ident, 0, 1, 0, C.byref(comm)))
+    sc = scenes.cornell(32, 24)
+    rm = render.RenderingManager(render.RenderParameters())
+    rm.start_rendering(sc)
+    rm.render(2)
+    before = rm.get_pass("beauty")
+    abi.check(lib.er_gather_pass(rm.handle, abi.PASS_BEAUTY, comm, 0))
+    assert (rm.get_pass("beauty").view(np.uint32) == before.view(np.uint32)).all()
+    assert lib.er_gather_pass(rm.handle, abi.PASS_BEAUTY, comm, 3) == abi.ER_ERR_INVALID_ARG
+    rm.close()
+    lib.er_comm_destroy(comm)

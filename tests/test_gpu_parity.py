@@ -265,13 +265,13 @@ def test_edge_cases_bit_exact(oracle_mod, flags):
     compare(gpu_render(sc, 3, max_bounces=8, flags=flags), oracle_render(oracle_mod, sc, 3, max_bounces=8), what="degenerate soup")
 
 
-def _window_schedules_agree(sc, spp, max_bounces, rank, world, mega_ties=0.0):
+def _window_schedules_agree(sc, spp, max_bounces, rank, world, mega_ties=0.0, extra_flags=0):
     """wavefront == fused bit for bit (same traversal order); the megakernel walks the binary BVH, so on closed
     meshes it may resolve an exact distance tie on a shared edge the other way (`mega_ties` = tolerated pixel fraction;
     the two pixels found on C4 were checked against the oracle in both of its traversal orders: wavefront's answer)."""
-    w = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_WAVEFRONT)
-    f = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_FUSED)
-    m = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_MEGAKERNEL)
+    w = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_WAVEFRONT | extra_flags)
+    f = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_FUSED | extra_flags)
+    m = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_MEGAKERNEL | extra_flags)
     owned = w["samples"].reshape(w["beauty"].shape[:2]) > 1
     for p in ("beauty", "normal", "tangent", "bitangent"):
         assert (w[p].view(np.uint32) == f[p].view(np.uint32)).all(), p
@@ -286,7 +286,8 @@ def _window_schedules_agree(sc, spp, max_bounces, rank, world, mega_ties=0.0):
 
 def test_c5_full_size_properties():
     """BASELINE config 5 at full size: 1M triangles, 64 materials with 192 value-noise textures of 256x256, clearcoat /
-    anisotropic / sheen variants, 16 bounces, 1920x1080 (point lights: the reference defines no result).
+    anisotropic / sheen variants, 16 bounces, 1920x1080, reference behaviour (the descriptor's 256 point lights are ignored
+    without ER_FLAG_POINT_LIGHTS; the lit configuration runs in tests/test_gpu_lights.py).
     The three schedules agree bit for bit on a window of tiles; chunked calls equal one call on that window."""
     sc = scenes.torture(1_000_000, 1920, 1080, seed=12345)
     w = _window_schedules_agree(sc, 2, 16, rank=5, world=48)
