@@ -180,6 +180,9 @@ public:
         const Camera& c = scene->camera;
         d.camera = ErCamera{c.focalLength, c.sensorWidth, c.sensorHeight, c.aperture, c.focusDistance,
                             {c.rotation.x, c.rotation.y, c.rotation.z}, c.bokeh ? 1 : 0, {c.position.x, c.position.y, c.position.z}};
+        std::vector<ErPointLight> pls;      // evaluated only with ER_FLAG_POINT_LIGHTS (src/PointLight.h:4-16; no reference command loads one)
+        for (const PointLight& p : scene->pointLights) pls.push_back(ErPointLight{{p.position.x, p.position.y, p.position.z}, {p.radiance.x, p.radiance.y, p.radiance.z}});
+        d.point_light_count = (uint32_t)pls.size(); d.point_lights = pls.empty() ? nullptr : pls.data();
         d.x_res = scene->x_res; d.y_res = scene->y_res;
         pars.width = scene->x_res; pars.height = scene->y_res;
         check(er_scene_create(&d, &er_));
@@ -193,6 +196,7 @@ public:
     void render(unsigned n_samples) { check(er_render_samples(er_, n_samples)); }   // body of kernel_render_enqueue's loop
     std::vector<float> get_pass(const std::string& pass) {   // src/Managers.cpp:287-302
         std::vector<float> out((size_t)pars.width * pars.height * 4);
+        if (!er_) throw std::runtime_error("get_pass: no render has been started");
         check(er_read_pass(er_, parsePass(pass), out.data()));
         return out;
     }

@@ -1,18 +1,28 @@
-// eleven_obj.hpp -- OBJ text -> MeshObjects, dependency-free.
+// eleven_obj.hpp -- OBJ + MTL text -> MeshObjects / Materials, dependency-free.
 //
 // What the reference does at load time (reference src/ObjLoader.cpp:69-147): parse with rapidobj, triangulate,
 // flip z on positions and normals, normalise the normals, optionally recompute them face-weighted per position
-// (ObjLoader.cpp:53-66), take the material NAME per face (paired with the scene's materials later,
-// src/Scene.cpp:104-120), one MeshObject per shape, then generate tangents with MikkTSpace
-// (src/mikktspaceCallback.cpp:25-97).  rapidobj and MikkTSpace are third-party and absent here, so this is our own
-// reader with the same conventions; where the third-party code decides numbers, parity is UNPINNED:
+// (ObjLoader.cpp:53-66; its `faces` map is shared by ALL shapes of the file, so a later shape also sees the faces
+// earlier shapes put at a shared position -- mirrored here), take the material NAME per face (paired with the
+// scene's materials later, src/Scene.cpp:104-120), one MeshObject per shape, then generate tangents with MikkTSpace
+// (src/mikktspaceCallback.cpp:25-97: positions, SMOOTH normals and uvs in, per-corner tangent + one sign per
+// triangle out through set_tspace_basic).  rapidobj and MikkTSpace are third-party, un-vendored and absent here, so
+// this is our own reader with the same conventions; where the third-party code decides numbers parity is UNPINNED:
 //   * polygons are triangulated as a fan around their first corner (rapidobj fans convex polygons the same way);
-//   * tangents are per triangle, from the uv gradients: T = normalise(dP/du) orthogonalised against each corner
-//     normal, sign = handedness of (N, T, dP/dv) -- the quantities MikkTSpace averages per vertex; a face without
-//     usable uvs gets the normalised first edge.
+//   * tangents follow the published MikkTSpace construction (Mikkelsen 2008; mikktspace.c "genTangSpaceDefault"):
+//     per triangle dP/du from the uv gradients and an orientation flag (sign of the uv area); triangle corners that
+//     share position, normal AND uv, with the same orientation, form a group; within a group the triangles' dP/du,
+//     projected into the plane of the shared normal and normalised, are accumulated weighted by the corner's angle
+//     (measured between the edges projected into that plane) and normalised; sign = +1 where the uv mapping
+//     preserves orientation, -1 where it mirrors.  What is NOT reproduced: MikkTSpace's welding of nearly equal
+//     vertices, its edge-connectivity test when forming groups (here: exact equality of the three attributes) and its
+//     borrowing of tangents for degenerate triangles (here: the default (1,0,0) / first edge).
+// `parse_mtl` reads material libraries with the key handling of ObjLoader::parseMtl (src/ObjLoader.cpp:10-50).
 // Indices may be negative (relative), `v/vt/vn`, `v//vn`, `v/vt` and `v` are accepted; `o` and `g` start a new shape.
 #pragma once
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <istream>
 #include <map>
 #include <sstream>
@@ -40,6 +50,116 @@ struct PosLess {
     bool operator()(const Vector3& a, const Vector3& b) const { return std::tie(a.x, a.y, a.z) < std::tie(b.x, b.y, b.z); }
 };
 }  // namespace obj_detail
+
+// Per-corner tangents and the per-triangle sign of one MeshObject, the MikkTSpace way (see the header of this file).
+inline void generate_tangents(MeshObject& mo) {
+    using namespace obj_detail;
+    const size_t n = mo.tris.size();
+    struct Face { Vector3 os; bool orient; bool valid; };
+    std::vector<Face> faces(n);
+    for (size_t i = 0; i < n; i++) {
+        const Tri& t = mo.tris[i];
+        const Vector3 d1 = sub(t.vertices[1], t.vertices[0]), d2 = sub(t.vertices[2], t.vertices[0]);
+        const float s1 = t.uv[1].x - t.uv[0].x, t1 = t.uv[1].y - t.uv[0].y, s2 = t.uv[2].x - t.uv[0].x, t2 = t.uv[2].y - t.uv[0].y;
+        const float area2 = s1 * t2 - s2 * t1;                          // twice the signed uv area
+        Face f;
+        f.orient = area2 > 0;
+        f.os = sub(mul(d1, t2), mul(d2, t1));                           // dP/du scaled by the uv area (direction is what counts)
+        if (!f.orient) f.os = mul(f.os, -1.0f);
+        f.valid = std::fabs(area2) > 1e-30f && dot(f.os, f.os) > 0;
+        faces[i] = f;
+    }
+    // groups: corners with the same (position, normal, uv, orientation)
+    struct Key {
+        Vector3 p, nrm, uv;
+        bool orient;
+        bool operator<(const Key& o) const {
+            return std::tie(p.x, p.y, p.z, nrm.x, nrm.y, nrm.z, uv.x, uv.y, orient) < std::tie(o.p.x, o.p.y, o.p.z, o.nrm.x, o.nrm.y, o.nrm.z, o.uv.x, o.uv.y, o.orient);
+        }
+    };
+    std::map<Key, Vector3> groups;
+    auto corner_key = [&](size_t i, int j) { return Key{mo.tris[i].vertices[j], mo.tris[i].normals[j], mo.tris[i].uv[j], faces[i].orient}; };
+    auto in_plane = [](Vector3 v, Vector3 nrm) { return sub(v, mul(nrm, dot(nrm, v))); };
+    for (size_t i = 0; i < n; i++) {
+        if (!faces[i].valid) continue;
+        const Tri& t = mo.tris[i];
+        for (int j = 0; j < 3; j++) {
+            const Vector3 nrm = t.normals[j];
+            const Vector3 os = normalized(in_plane(faces[i].os, nrm));
+            // the corner's angle between its two edges, both projected into the plane of the normal
+            const Vector3 e0 = normalized(in_plane(sub(t.vertices[(j + 1) % 3], t.vertices[j]), nrm));
+            const Vector3 e1 = normalized(in_plane(sub(t.vertices[(j + 2) % 3], t.vertices[j]), nrm));
+            const float c = std::min(1.0f, std::max(-1.0f, dot(e0, e1)));
+            const float angle = std::acos(c);
+            Vector3& g = groups[corner_key(i, j)];
+            g = add(g, mul(os, angle));
+        }
+    }
+    for (size_t i = 0; i < n; i++) {
+        Tri& t = mo.tris[i];
+        for (int j = 0; j < 3; j++) {
+            Vector3 tg(1.0f, 0.0f, 0.0f);                                // MikkTSpace's default for a corner without a usable tangent
+            if (faces[i].valid) {
+                auto it = groups.find(corner_key(i, j));
+                if (it != groups.end() && dot(it->second, it->second) > 0) tg = normalized(it->second);
+            } else {
+                const Vector3 e = in_plane(sub(t.vertices[1], t.vertices[0]), t.normals[j]);
+                if (dot(e, e) > 0) tg = normalized(e);
+            }
+            t.tangents[j] = tg;
+        }
+        t.tangentsSign = (faces[i].orient || !faces[i].valid) ? 1.0f : -1.0f;    // set_tspace_basic: fSign, src/mikktspaceCallback.cpp:124-132
+    }
+}
+
+// A material library as ObjLoader::parseMtl reads it (reference src/ObjLoader.cpp:10-50): per `newmtl` block
+// Kd -> albedo, Ks -> specular (its first component), Ke -> emission, Ni -> eta, d -> opacity, and the map names
+// map_Kd / map_Ns / map_Bump / refl kept by keyword.  Everything else is ignored, as there.
+struct UnloadedMaterial {
+    Material mat;
+    std::map<std::string, std::string> maps;
+};
+inline std::vector<UnloadedMaterial> parse_mtl(std::istream& in) {
+    std::vector<UnloadedMaterial> out;
+    std::string line;
+    auto second_word = [](const std::string& l) {                        // getSecondWord, :5-8
+        std::string::size_type sp = l.find_first_of(" ");
+        std::string w = sp == std::string::npos ? std::string() : l.substr(sp + 1);
+        while (!w.empty() && (w.back() == '\r' || w.back() == ' ')) w.pop_back();
+        return w;
+    };
+    auto vec3 = [](const std::string& rest) {
+        Vector3 v;
+        std::istringstream ls(rest);
+        ls >> v.x >> v.y >> v.z;
+        return v;
+    };
+    while (std::getline(in, line)) {
+        size_t first = line.find_first_not_of(" \t");
+        if (first == std::string::npos) continue;
+        line = line.substr(first);
+        if (line.compare(0, 6, "newmtl") == 0) {
+            UnloadedMaterial u;
+            u.mat.name = second_word(line);
+            out.push_back(u);
+            continue;
+        }
+        if (out.empty() || line.size() < 2) continue;
+        UnloadedMaterial& u = out.back();
+        if (line[0] == 'K' && line[1] == 'd') u.mat.albedo = vec3(line.substr(2));               // :23-25
+        if (line[0] == 'K' && line[1] == 's') u.mat.specular = vec3(line.substr(2)).x;          // :27-29
+        if (line[0] == 'K' && line[1] == 'e') u.mat.emission = vec3(line.substr(2));            // :31-33
+        if (line[0] == 'N' && line[1] == 'i') u.mat.eta = std::strtof(second_word(line).c_str(), nullptr);       // :35-37
+        if (line[0] == 'd' && (line[1] == ' ' || line[1] == '\t')) u.mat.opacity = std::strtof(second_word(line).c_str(), nullptr);   // :39-41
+        for (const char* name : {"map_Kd", "map_Ns", "map_Bump", "refl"})                         // :42-48
+            if (line.find(name) != std::string::npos) u.maps[name] = second_word(line);
+    }
+    return out;
+}
+inline std::vector<UnloadedMaterial> parse_mtl(const std::string& text) {
+    std::istringstream in(text);
+    return parse_mtl(in);
+}
 
 // Parses OBJ text.  recompute_normals: the reference's face-weighted recomputation (its default for `load_object`).
 inline std::vector<MeshObject> load_obj(std::istream& in, bool recompute_normals = false) {
@@ -96,10 +216,12 @@ inline std::vector<MeshObject> load_obj(std::istream& in, bool recompute_normals
         }
     }
     flush();
+    // normals: face-weighted per position (ObjLoader.cpp:53-66), or the face normal where the file gave none.  The
+    // reference's `faces` map lives across the shapes of one file (:77) and a shape's normals are recomputed right
+    // after the shape is read (:136-137): shape k sees the faces of shapes 0..k.
+    std::map<Vector3, Vector3, PosLess> acc;
     for (MeshObject& mo : out) {
-        // normals: face-weighted per position (ObjLoader.cpp:53-66), or the face normal where the file gave none
         if (recompute_normals) {
-            std::map<Vector3, Vector3, PosLess> acc;
             for (const Tri& t : mo.tris) {
                 Vector3 fn = cross(sub(t.vertices[2], t.vertices[0]), sub(t.vertices[1], t.vertices[0]));   // cross(edge2, edge1), :61-63
                 for (int j = 0; j < 3; j++) acc[t.vertices[j]] = add(acc[t.vertices[j]], fn);
@@ -111,25 +233,7 @@ inline std::vector<MeshObject> load_obj(std::istream& in, bool recompute_normals
                 for (int j = 0; j < 3; j++) if (dot(t.normals[j], t.normals[j]) == 0) t.normals[j] = fn;
             }
         }
-        // tangents
-        for (Tri& t : mo.tris) {
-            const Vector3 e1 = sub(t.vertices[1], t.vertices[0]), e2 = sub(t.vertices[2], t.vertices[0]);
-            const float du1 = t.uv[1].x - t.uv[0].x, dv1 = t.uv[1].y - t.uv[0].y, du2 = t.uv[2].x - t.uv[0].x, dv2 = t.uv[2].y - t.uv[0].y;
-            const float det = du1 * dv2 - du2 * dv1;
-            Vector3 dpdu = e1, dpdv = e2;
-            if (std::fabs(det) > 1e-20f) {
-                dpdu = mul(sub(mul(e1, dv2), mul(e2, dv1)), 1.0f / det);
-                dpdv = mul(sub(mul(e2, du1), mul(e1, du2)), 1.0f / det);
-            }
-            const Vector3 fn = normalized(cross(e1, e2));
-            for (int j = 0; j < 3; j++) {
-                const Vector3 n = t.normals[j];
-                Vector3 tg = sub(dpdu, mul(n, dot(n, dpdu)));
-                if (dot(tg, tg) == 0) tg = e1;
-                t.tangents[j] = normalized(tg);
-            }
-            t.tangentsSign = dot(cross(fn, dpdu), dpdv) < 0 ? -1.0f : 1.0f;
-        }
+        generate_tangents(mo);          // CalcTangents::calc(mo), ObjLoader.cpp:141-142
     }
     return out;
 }

@@ -83,4 +83,5 @@ def test_c5_full_size_with_its_256_lights_and_mis():
     assert np.isfinite(w["beauty"]).all() and w["beauty"][..., :3].max() <= 10
     plain = gpu_render(sc, 2, max_bounces=16, rank=5, world=48)
     assert w["counters"]["rays"] > plain["counters"]["rays"]           # the light queries
-    assert (w["beauty"].view(np.uint32) != plain["beauty"].view(np.uint32)).any(-1).mean() > 0.2
+    owned = plain["samples"].reshape(plain["beauty"].shape[:2]) > 1
+    assert (w["beauty"].view(np.uint32) != plain["beauty"].view(np.uint32)).any(-1)[owned].mean() > 0.2

@@ -8,6 +8,7 @@ import os
 import subprocess
 
 import numpy as np
+import pytest
 
 from elevenrender_amd import scenes
 
@@ -70,8 +71,15 @@ def test_cornell_obj_round_trip(tmp_path):
     tang = c[:, :, 8:11]
     assert np.allclose(np.linalg.norm(tang, axis=-1), 1.0, atol=1e-5)
     assert np.abs((tang * c[:, :, 3:6]).sum(-1)).max() < 1e-5
-    assert np.allclose(tang, sc.tangents.reshape(-1, 3, 3), atol=1e-5)      # uv (0,0),(1,0),(0,1): dP/du is the first edge
-    assert (np.abs(signs) == 1).all()
+    # every triangle has uv (0,0),(1,0),(0,1): dP/du is its first edge.  Corners 1 and 2 are alone in their
+    # (position, normal, uv) group and get exactly that; corner 0 is shared by the quad's two triangles with the SAME
+    # uv, so MikkTSpace-style grouping blends their two first edges, weighted by the corner angles (45 degrees each)
+    ref = sc.tangents.reshape(-1, 3, 3)
+    assert np.allclose(tang[:, 1:], ref[:, 1:], atol=1e-5)
+    pair = ref[0::2, 0] + ref[1::2, 0]
+    pair /= np.linalg.norm(pair, axis=-1, keepdims=True)
+    assert np.allclose(tang[0::2, 0], pair, atol=1e-5) and np.allclose(tang[1::2, 0], pair, atol=1e-5)
+    assert (signs == 1).all()
 
 
 def test_polygons_missing_attributes_and_recomputed_normals(tmp_path):
@@ -84,3 +92,94 @@ def test_polygons_missing_attributes_and_recomputed_normals(tmp_path):
     n = c[:, :, 3:6]
     assert np.allclose(np.linalg.norm(n, axis=-1), 1.0, atol=1e-6)     # recomputed, face-weighted per position
     assert np.allclose(n[0, 2], [0, 0, -1]) or np.allclose(n[0, 2], [0, 0, 1])
+
+
+def test_mikktspace_style_tangents_on_a_uv_mapped_cube(tmp_path):
+    """Hand-computable case: a cube whose faces carry the unit uv square.  On every face the tangent of every corner is
+    the direction of increasing u (exactly: both triangles of a face agree, so the angle-weighted blend is that
+    direction), it is orthogonal to the face normal, and the sign is +1 where (T, dP/dv, N) is right-handed in uv
+    orientation and -1 on the faces whose uv square is mirrored."""
+    path = str(tmp_path / "cube.obj")
+    faces = []   # (origin, u axis, v axis): corner = o + a*U + b*V, uv = (a, b)
+    for axis in range(3):
+        for sgn in (0.0, 1.0):
+            o = np.zeros(3); o[axis] = sgn
+            U = np.zeros(3); U[(axis + 1) % 3] = 1
+            V = np.zeros(3); V[(axis + 2) % 3] = 1
+            faces.append((o, U, V))
+    with open(path, "w") as f:
+        f.write("o cube\n")
+        for k, (o, U, V) in enumerate(faces):
+            mirrored = k % 2 == 1
+            for a, b in ((0, 0), (1, 0), (1, 1), (0, 1)):
+                p = o + a * U + b * V
+                f.write("v %g %g %g\n" % (p[0], p[1], -p[2]))                # the loader flips z back
+                f.write("vt %g %g\n" % ((1 - a) if mirrored else a, b))
+            n = np.cross(U, V)
+            f.write("vn %g %g %g\n" % (n[0], n[1], -n[2]))
+            q = 4 * k
+            f.write("f %d/%d/%d %d/%d/%d %d/%d/%d %d/%d/%d\n" % (q + 1, q + 1, k + 1, q + 2, q + 2, k + 1, q + 3, q + 3, k + 1, q + 4, q + 4, k + 1))
+    c, signs, mats = parse(subprocess.check_output([build(), path], text=True))
+    assert c.shape[0] == 12
+    for k, (o, U, V) in enumerate(faces):
+        mirrored = k % 2 == 1
+        want = -U if mirrored else U
+        for t in (2 * k, 2 * k + 1):
+            assert np.allclose(c[t, :, 8:11], want, atol=1e-6), (k, c[t, :, 8:11])
+            assert signs[t] == (-1.0 if mirrored else 1.0)
+            assert np.abs((c[t, :, 8:11] * c[t, :, 3:6]).sum(-1)).max() < 1e-6
+
+
+def test_mikktspace_style_tangents_on_a_smooth_sphere(tmp_path):
+    """A latitude-longitude sphere with smooth normals and u = longitude: away from the poles every vertex's tangent is
+    the unit east vector d/d(longitude), shared by all (six) triangles that meet there, orthogonal to the normal."""
+    path = str(tmp_path / "sphere.obj")
+    nu, nv = 24, 12
+    with open(path, "w") as f:
+        f.write("o sphere\n")
+        for j in range(nv + 1):
+            th = np.pi * j / nv
+            for i in range(nu + 1):                     # the seam column is duplicated so uvs stay monotone
+                ph = 2 * np.pi * i / nu
+                p = np.array([np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)])
+                f.write("v %.9g %.9g %.9g\nvn %.9g %.9g %.9g\nvt %.9g %.9g\n" % (p[0], p[1], -p[2], p[0], p[1], -p[2], i / nu, j / nv))
+        idx = lambda i, j: j * (nu + 1) + i + 1
+        for j in range(1, nv - 1):                      # skip the polar caps (degenerate uv there)
+            for i in range(nu):
+                a, b, c_, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
+                f.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a, a, a, b, b, b, c_, c_, c_))
+                f.write("f %d/%d/%d %d/%d/%d %d/%d/%d\n" % (a, a, a, c_, c_, c_, d, d, d))
+    c, signs, mats = parse(subprocess.check_output([build(), path], text=True))
+    pos, nrm, tang = c[:, :, 0:3].reshape(-1, 3), c[:, :, 3:6].reshape(-1, 3), c[:, :, 8:11].reshape(-1, 3)
+    east = np.stack([-pos[:, 2], np.zeros(len(pos)), pos[:, 0]], -1)        # d/d(longitude) of (sin th cos ph, cos th, sin th sin ph)
+    east /= np.linalg.norm(east, axis=-1, keepdims=True)
+    interior = (np.abs(pos[:, 1]) < np.cos(np.pi * 1.5 / nv))               # vertices whose whole fan is in the mesh
+    seam = (np.abs(pos[:, 2]) < 1e-6) & (pos[:, 0] > 0)                     # longitude 0 = 2 pi: two uv values, so two half-fan groups
+    assert (interior & ~seam).sum() > 1000
+    assert (np.abs((tang * nrm).sum(-1)) < 1e-5).all()
+    assert ((tang[interior & ~seam] * east[interior & ~seam]).sum(-1) > 0.9999).all()
+    assert ((tang[interior & seam] * east[interior & seam]).sum(-1) > 0.99).all()      # half a fan: biased by half a segment
+    assert len(set(signs.tolist())) == 1                                    # one orientation everywhere
+    # the same vertex gets the same tangent in every triangle that uses it
+    key = np.round(c[:, :, 0:8].reshape(-1, 8), 6)
+    _, inv = np.unique(key, axis=0, return_inverse=True)
+    for g in np.unique(inv.reshape(-1))[:200]:
+        m = inv.reshape(-1) == g
+        assert np.abs(tang[m] - tang[m][0]).max() < 1e-6
+
+
+def test_mtl_reader_key_handling(tmp_path):
+    """parse_mtl against the reference's ObjLoader::parseMtl rules (src/ObjLoader.cpp:10-50)."""
+    path = str(tmp_path / "m.mtl")
+    with open(path, "w") as f:
+        f.write("# comment\nnewmtl red\nNs 96\nKa 1 1 1\nKd 0.8 0.1 0.1\nKs 0.25 0.5 0.75\nKe 0 0 0\nNi 1.45\nd 0.5\nillum 2\n"
+                "map_Kd wood.png\nmap_Bump bump.png\n\nnewmtl lamp\nKe 5 4 3\nrefl env.hdr\nmap_Ns gloss.png\n")
+    out = subprocess.check_output([build(), "--mtl", path], text=True).splitlines()
+    assert out[0].split()[:2] == ["m", "red"]
+    red = dict(zip(out[0].split()[2::2], out[0].split()[3::2]))
+    assert [float(v) for v in red["Kd"].split(",")] == pytest.approx([0.8, 0.1, 0.1])
+    assert float(red["specular"]) == pytest.approx(0.25) and float(red["eta"]) == pytest.approx(1.45) and float(red["opacity"]) == pytest.approx(0.5)
+    assert red["map_Kd"] == "wood.png" and red["map_Bump"] == "bump.png"
+    lamp = dict(zip(out[1].split()[2::2], out[1].split()[3::2]))
+    assert [float(v) for v in lamp["Ke"].split(",")] == pytest.approx([5, 4, 3]) and lamp["refl"] == "env.hdr" and lamp["map_Ns"] == "gloss.png"
+    assert float(lamp["opacity"]) == 1.0 and float(lamp["specular"]) == 0.5      # Material defaults (src/Material.h:20-47)
