@@ -44,21 +44,28 @@ def test_cpp_host_mirror_matches_python_mirror():
 
 
 @pytest.mark.gpu
-def test_obj_file_through_cpp_host_gives_the_same_image(tmp_path):
+def test_obj_file_through_cpp_host_against_the_oracle(tmp_path, oracle_mod):
     """BASELINE config 1 names a Cornell-box .obj: the box written as OBJ text, read by eleven::load_obj
-    (elevenrender_amd/host/eleven_obj.hpp) and rendered through the C++ host mirror equals the generated scene."""
-    from test_obj_cpu import write_obj
+    (elevenrender_amd/host/eleven_obj.hpp) and rendered through the C++ host mirror, against the ORACLE fed the arrays the
+    loader produced (dumped by tests/native/obj_dump: positions, normals, uvs and the MikkTSpace-style tangents) -- not
+    against another run of the HIP path."""
+    from test_obj_cpu import build as build_dump, parse, write_obj
+    from elevenrender_amd import abi
     sc = scenes.cornell(48, 48)
     path = str(tmp_path / "cornell.obj")
-    write_obj(path, sc, names=["default", "red", "green", "light"])
+    names = ["default", "red", "green", "light"]
+    write_obj(path, sc, names=names)
     exe = build("host_cornell")
     out = subprocess.check_output([exe, "48", "5", path], text=True)
-    rm = render.RenderingManager()
-    rm.start_rendering(sc)
-    rm.render(5)
-    img = rm.get_pass("beauty")
-    rm.close()
-    assert f"fnv1a {fnv1a(img):016x}" in out, out
+    c, signs, mats = parse(subprocess.check_output([build_dump(), path], text=True))
+    loaded = abi.SceneData(c[:, :, 0:3], c[:, :, 3:6], c[:, :, 8:11], c[:, :, 6:8], signs, np.array([names.index(m) for m in mats], np.int32),
+                           sc.materials, camera=sc.camera, x_res=48, y_res=48)
+    assert not np.allclose(loaded.tangents, sc.tangents)          # shared quad corners are blended: a different scene from the generated one
+    o = oracle_mod.Oracle(loaded, math_mode=oracle_mod.MATH_ER, max_bounces=5, threads=4)
+    o.render(5)
+    ref = o.read_pass(0)
+    o.close()
+    assert f"fnv1a {fnv1a(ref):016x}" in out, out
 
 
 @pytest.mark.gpu
