@@ -60,6 +60,16 @@ with open(os.path.join(dst, f"{tag}_pmc_valu.csv"), "w", newline="") as f:
         util = tc / (64.0 * av) if av else 0.0
         w.writerow([k, n, int(iv), int(av), int(tc), int(ga), round(busy, 3), round(util, 3)])
 
+l2_path = os.path.join(src, "pmc_l2", "run_counter_collection.csv")
+if os.path.exists(l2_path):
+    l2 = per_kernel(l2_path)
+    with open(os.path.join(dst, f"{tag}_pmc_l2.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "launches", "TCC_HIT_sum", "TCC_MISS_sum", "l2_hit_rate = HIT / (HIT + MISS)"])
+        for k, d in sorted(l2.items()):
+            h, m = d["TCC_HIT_sum"][1], d["TCC_MISS_sum"][1]
+            w.writerow([k, d["TCC_HIT_sum"][0], int(h), int(m), round(h / (h + m), 4) if h + m else 0.0])
+
 key = [k for k in traffic if k.startswith("er_wf_trace<false>")]
 out = {"er_wf_trace_hbm_bytes_per_launch": traffic[key[0]] if key else None,
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes = 2*FETCH_SIZE(KB)*1024 + WRITE_SIZE(KB)*1024 "
