@@ -210,7 +210,8 @@ def main():
         rm_.start_rendering(scene)
         return rm_
 
-    rm = manager(abi.FLAG_PROFILE)
+    # (ER_BENCH_NO_PROFILE=1, diagnostic: time the region without the per-launch HIP events of ER_FLAG_PROFILE)
+    rm = manager(0 if os.environ.get("ER_BENCH_NO_PROFILE") == "1" else abi.FLAG_PROFILE)
     accel = rm.accel_info()
 
     def sync_all():
@@ -256,11 +257,27 @@ def main():
             erdist.gather_all_planes_torch(dist, rm, rank, world)     # gloo on the host: the test harness path
             gather_path = "torch.distributed (gloo rehearsal)"
         else:
-            comm = erdist.NativeComm(dist, rank, world, local_rank)   # RCCL communicator made by the library's C++ side
-            for p in range(abi.PASS_COUNT):
-                comm.gather_pass(rm, p)                               # er_gather_pass: pack -> ncclSend/ncclRecv -> unpack
-            comm.close()
-            gather_path = "er_gather_pass (RCCL from the C++ side, 5 planes)"
+            # the production combine: RCCL communicator made by the library's C++ side (er_comm_create), then per plane
+            # er_gather_pass = pack -> ncclSend / ncclRecv over xGMI -> unpack.  If the C++ path cannot start on this
+            # node (RCCL not loadable ...) every rank falls back to the torch.distributed gather so that the line is
+            # not lost; `gather` says which path ran.
+            ok = torch.ones(1, dtype=torch.int32, device="cuda")
+            comm = None
+            try:
+                comm = erdist.NativeComm(dist, rank, world, local_rank)
+            except Exception as e:
+                print(f"[rank {rank}] er_comm_create failed: {e}", file=sys.stderr)
+                ok.zero_()
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                for p in range(abi.PASS_COUNT):
+                    comm.gather_pass(rm, p)
+                gather_path = "er_gather_pass (RCCL from the C++ side, 5 planes)"
+            else:
+                erdist.gather_all_planes_torch(dist, rm, rank, world)
+                gather_path = "torch.distributed.gather (fallback: er_comm_create failed)"
+            if comm is not None:
+                comm.close()
         torch.cuda.synchronize()
     beauty_mean = None
     if rank == 0:

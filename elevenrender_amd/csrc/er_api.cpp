@@ -229,9 +229,9 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         memset(&isect[n], 0, sizeof(ErTriIsect));
         // wide nodes and triangle records share ONE buffer: the wide traversal addresses both with a 32-bit
         // offset in 16-byte units
-        n8_pieces = bvh.nodes8.size() * 5 + 3;   // + padding: a step fetches 96 B from a node's start
+        n8_pieces = bvh.nodes8.size() * ER_NODE8_PIECES + 8;   // + padding: a step fetches 96 B from a node's start
         geom.assign(n8_pieces + (n + 1) * 3, make_float4(0, 0, 0, 0));
-        if (!bvh.nodes8.empty()) memcpy(geom.data(), bvh.nodes8.data(), bvh.nodes8.size() * sizeof(ErNode8));
+        for (size_t k = 0; k < bvh.nodes8.size(); k++) memcpy(geom.data() + k * ER_NODE8_PIECES, &bvh.nodes8[k], sizeof(ErNode8));
         memcpy(geom.data() + n8_pieces, isect.data(), (n + 1) * sizeof(ErTriIsect));
         if (geom.size() >= (1ull << 30)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: geometry exceeds the 16 GB addressable by the wide traversal");
         if ((rc = upload(s->d_nodes8, geom.data(), geom.size(), s->stream)) != ER_OK) return rc;

@@ -63,6 +63,11 @@ struct ErNode8 {            // 80 bytes = five 16-byte loads
     uint8_t qhi[3][8];
 };
 static_assert(sizeof(ErNode8) == 80, "wide node must be 80 bytes");
+// Stride of the wide nodes in the traversal buffer, in 16-byte pieces: 5 = packed (80 B; every second node straddles two
+// 128-byte cache lines), 8 = one node per 128-byte line.
+#ifndef ER_NODE8_PIECES
+#define ER_NODE8_PIECES 5
+#endif
 static_assert(ER_BVH_LEAF_MAX <= 2, "ErNode8::tri_present has two bits per child slot");
 
 struct ErBvhBuild {

@@ -55,42 +55,7 @@ void er_launch_debug_trace(const DevScene& S, const float* o, const float* d, ui
     hipLaunchKernelGGL(er_debug_trace_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, S, o, d, n, self, limit, tri, slot, pos, dist, info, (uint2*)spill);
 }
 
-// ---- per-bounce trace of one pixel-sample: bounce_step (er_shade.h) + the production traversal, queries traced at once ----
-namespace {
-
-struct PixelSink {
-    const DevScene& S;
-    uint2* stack;
-    uint2* spill;
-    int* stack2;
-    F3& light;
-    F3 &aov_n, &aov_t, &aov_b;
-    ErTraceRec* rec;
-    unsigned &c_rays, &c_nodes, &c_tris;
-    ERD int tri_id(int slot) const { return slot < 0 ? -1 : __builtin_bit_cast(int, S.tri_isect[(size_t)slot * 3].w); }
-    ERD void hdri_query(const Ray& sr, int self_slot, float d_self, F3 c_vis, F3 c_occ) {
-        int info;
-        c_rays++;
-        const bool occ = trav_run_shadow<false>(S, stack, spill, stack2, sr, self_slot, d_self, info, c_nodes, c_tris);
-        light = light + (occ ? c_occ : c_vis);
-        if (rec) {
-            rec->shadow_occ = occ ? 1 : 0;
-            // what the reference's throwRay(shadowRay) returns (src/kernel.cpp:556), for the record only
-            rec->shadow_tri = tri_id(trav_run_closest<false>(S, stack, spill, stack2, sr, __builtin_inff(), info, c_nodes, c_tris));
-        }
-    }
-    ERD void light_query(const Ray& lr, float limit, F3 l_vis, F3 l_occ) {
-        int info;
-        c_rays++;
-        const bool occ = trav_run_shadow<false>(S, stack, spill, stack2, lr, -1, limit, info, c_nodes, c_tris);
-        light = light + (occ ? l_occ : l_vis);
-        if (rec) rec->light_occ = occ ? 1 : 0;
-    }
-    ERD void first_hit(F3 n, F3 t, F3 b) { aov_n = n; aov_t = t; aov_b = b; }
-};
-
-}  // namespace
-
+// ---- per-bounce trace of one pixel-sample: er_bounce.inc over the production traversal, queries traced at once ----
 template <bool EXT>
 __global__ __launch_bounds__(64) void er_debug_pixel_kernel(DevScene S, uint32_t idx, ErTraceRec* recs, int max_recs, int* count, uint2* spill) {
     // (one lane, speed irrelevant: all three traversal stacks live in the HBM scratch buffer)
@@ -122,17 +87,47 @@ __global__ __launch_bounds__(64) void er_debug_pixel_kernel(DevScene S, uint32_t
                 rec->position[0] = h.position.x; rec->position[1] = h.position.y; rec->position[2] = h.position.z;
             }
         }
-        BounceOut bo;
-        PixelSink sink{S, s_stack, spill, s_stack2, light, aov_n, aov_t, aov_b, rec, c_rays, c_nodes, c_tris};
-        bounce_step<false, EXT>(S, ray, hslot, rs, light, reduction, bounce, prev_pdf, bo, sink, c_shaded, c_texels, c_hdri);
+        constexpr bool COUNT = false;
+        const Ray traced = ray;
+        const uint32_t rs_before = rs;
+        bool done = false, pending = false, lpending = false;
+#define ER_BOUNCE_HDRI_QUERY(sr, self_slot, d_self, cv, co)                                                                          \
+    {                                                                                                                                 \
+        int info_;                                                                                                                    \
+        c_rays++;                                                                                                                     \
+        const bool occ_ = trav_run_shadow<false>(S, s_stack, spill, s_stack2, (sr), (self_slot), (d_self), info_, c_nodes, c_tris);   \
+        light = light + (occ_ ? (co) : (cv));                                                                                         \
+        if (rec) {                                                                                                                    \
+            rec->shadow_occ = occ_ ? 1 : 0;                                                                                           \
+            /* what the reference's throwRay(shadowRay) returns (src/kernel.cpp:556), for the record only */                          \
+            const int cs_ = trav_run_closest<false>(S, s_stack, spill, s_stack2, (sr), __builtin_inff(), info_, c_nodes, c_tris);     \
+            rec->shadow_tri = cs_ < 0 ? -1 : __builtin_bit_cast(int, S.tri_isect[(size_t)cs_ * 3].w);                                 \
+        }                                                                                                                             \
+    }
+#define ER_BOUNCE_LIGHT_QUERY(lr, limit, lv, lo)                                                                                     \
+    {                                                                                                                                 \
+        int info_;                                                                                                                    \
+        c_rays++;                                                                                                                     \
+        const bool occ_ = trav_run_shadow<false>(S, s_stack, spill, s_stack2, (lr), -1, (limit), info_, c_nodes, c_tris);             \
+        light = light + (occ_ ? (lo) : (lv));                                                                                         \
+        if (rec) rec->light_occ = occ_ ? 1 : 0;                                                                                       \
+    }
+#define ER_BOUNCE_FIRST_HIT(n, t, b) aov_n = (n); aov_t = (t); aov_b = (b)
+#include "er_bounce.inc"
+#undef ER_BOUNCE_HDRI_QUERY
+#undef ER_BOUNCE_LIGHT_QUERY
+#undef ER_BOUNCE_FIRST_HIT
+        (void)pending; (void)lpending; (void)traced;
         if (rec) {
-            rec->opaque = bo.opaque ? 1 : 0;
-            if (hslot >= 0) { rec->wi[0] = bo.next.d.x; rec->wi[1] = bo.next.d.y; rec->wi[2] = bo.next.d.z; }
+            // the opacity test passed iff more than its one draw was taken (src/kernel.cpp:539: the opaque branch draws 4+)
+            uint32_t r1 = rs_before;
+            (void)rng_next(r1);
+            rec->opaque = (hslot >= 0 && rs != r1) ? 1 : 0;
+            if (hslot >= 0) { rec->wi[0] = ray.d.x; rec->wi[1] = ray.d.y; rec->wi[2] = ray.d.z; }
             rec->light[0] = light.x; rec->light[1] = light.y; rec->light[2] = light.z;
             rec->reduction[0] = reduction.x; rec->reduction[1] = reduction.y; rec->reduction[2] = reduction.z;
         }
-        if (bo.done) break;
-        ray = bo.next;
+        if (done) break;
     }
     const uint32_t sa = S.samples[idx];
     const uint32_t sa2 = accumulate_sample(S, idx, sa, light, aov_n, aov_t, aov_b);

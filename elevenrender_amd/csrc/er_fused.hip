@@ -65,32 +65,6 @@ __device__ __forceinline__ unsigned fwave_sum(unsigned v) {
 #define PK_LLIM 19
 #define PK_LVIS 20
 #define PK_LOCC 23
-// the fused schedule's sink (er_shade.h): queries and AOVs are parked in the lane's LDS columns
-struct FusedSink {
-    float* park;
-    float* aov;
-    float* job;
-    ERD void hdri_query(const Ray& sr, int self_slot, float d_self, F3 c_vis, F3 c_occ) {
-        job[0] = sr.o.x; job[64] = sr.o.y; job[128] = sr.o.z;
-        job[192] = sr.d.x; job[256] = sr.d.y; job[320] = sr.d.z;
-        job[384] = __builtin_bit_cast(float, self_slot); job[448] = d_self;
-        park[PK_CVIS * 64] = c_vis.x; park[(PK_CVIS + 1) * 64] = c_vis.y; park[(PK_CVIS + 2) * 64] = c_vis.z;
-        park[PK_COCC * 64] = c_occ.x; park[(PK_COCC + 1) * 64] = c_occ.y; park[(PK_COCC + 2) * 64] = c_occ.z;
-    }
-    ERD void light_query(const Ray& lr, float limit, F3 l_vis, F3 l_occ) {
-        park[PK_LRAY * 64] = lr.o.x; park[(PK_LRAY + 1) * 64] = lr.o.y; park[(PK_LRAY + 2) * 64] = lr.o.z;
-        park[(PK_LRAY + 3) * 64] = lr.d.x; park[(PK_LRAY + 4) * 64] = lr.d.y; park[(PK_LRAY + 5) * 64] = lr.d.z;
-        park[PK_LLIM * 64] = limit;
-        park[PK_LVIS * 64] = l_vis.x; park[(PK_LVIS + 1) * 64] = l_vis.y; park[(PK_LVIS + 2) * 64] = l_vis.z;
-        park[PK_LOCC * 64] = l_occ.x; park[(PK_LOCC + 1) * 64] = l_occ.y; park[(PK_LOCC + 2) * 64] = l_occ.z;
-    }
-    ERD void first_hit(F3 n, F3 t, F3 b) {
-        aov[0] = n.x; aov[64] = n.y; aov[128] = n.z;
-        aov[192] = t.x; aov[256] = t.y; aov[320] = t.z;
-        aov[384] = b.x; aov[448] = b.y; aov[512] = b.z;
-    }
-};
-
 template <bool COUNT, bool LIGHTS>   // LIGHTS = the EXT of er_shade.h (point lights and / or MIS)
 __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, uint2* ring_base, uint2* spill_base, uint32_t n_samples) {
     __shared__ uint2 s_stack[WF_LDS_STACK * 64];
@@ -227,10 +201,35 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
                                                              T.overflow ? -2 : ((T.s0 >= 0 && T.s1 >= 0) ? T.s1 : -1), c_nodes, c_tris);
                     c_bounce++;
                     float prev_pdf = LIGHTS ? park[PK_PDF * 64] : -1.0f;
-                    BounceOut bo;
-                    FusedSink sink{park, aov, s_job + lane};
-                    bounce_step<COUNT, LIGHTS>(S, ray, hslot, rs, light, reduction, bounce, prev_pdf, bo, sink, c_shaded, c_texels, c_hdri);
+                    bool done = false, pending = false, lpending = false;
+                    constexpr bool EXT = LIGHTS;
+                    float* job = s_job + lane;
+                    // the hooks park the queries (and the AOVs) in this lane's LDS columns
+#define ER_BOUNCE_HDRI_QUERY(sr, self_slot, d_self, cv, co)                                                          \
+    job[0] = (sr).o.x; job[64] = (sr).o.y; job[128] = (sr).o.z;                                                       \
+    job[192] = (sr).d.x; job[256] = (sr).d.y; job[320] = (sr).d.z;                                                    \
+    job[384] = __builtin_bit_cast(float, (int)(self_slot)); job[448] = (d_self);                                      \
+    park[PK_CVIS * 64] = (cv).x; park[(PK_CVIS + 1) * 64] = (cv).y; park[(PK_CVIS + 2) * 64] = (cv).z;                \
+    park[PK_COCC * 64] = (co).x; park[(PK_COCC + 1) * 64] = (co).y; park[(PK_COCC + 2) * 64] = (co).z
+#define ER_BOUNCE_LIGHT_QUERY(lr, limit, lv, lo)                                                                     \
+    {                                                                                                                 \
+        const F3 lv_ = (lv), lo_ = (lo);                                                                              \
+        park[PK_LRAY * 64] = (lr).o.x; park[(PK_LRAY + 1) * 64] = (lr).o.y; park[(PK_LRAY + 2) * 64] = (lr).o.z;      \
+        park[(PK_LRAY + 3) * 64] = (lr).d.x; park[(PK_LRAY + 4) * 64] = (lr).d.y; park[(PK_LRAY + 5) * 64] = (lr).d.z; \
+        park[PK_LLIM * 64] = (limit);                                                                                 \
+        park[PK_LVIS * 64] = lv_.x; park[(PK_LVIS + 1) * 64] = lv_.y; park[(PK_LVIS + 2) * 64] = lv_.z;                \
+        park[PK_LOCC * 64] = lo_.x; park[(PK_LOCC + 1) * 64] = lo_.y; park[(PK_LOCC + 2) * 64] = lo_.z;                \
+    }
+#define ER_BOUNCE_FIRST_HIT(n, t, b)                                                                                 \
+    aov[0] = (n).x; aov[64] = (n).y; aov[128] = (n).z;                                                                \
+    aov[192] = (t).x; aov[256] = (t).y; aov[320] = (t).z;                                                             \
+    aov[384] = (b).x; aov[448] = (b).y; aov[512] = (b).z
+#include "er_bounce.inc"
+#undef ER_BOUNCE_HDRI_QUERY
+#undef ER_BOUNCE_LIGHT_QUERY
+#undef ER_BOUNCE_FIRST_HIT
                     if (LIGHTS) park[PK_PDF * 64] = prev_pdf;
+                    struct { bool done, shadow, lshadow; Ray next; } bo = {done, pending, lpending, ray};
                     const bool lsh = LIGHTS && bo.lshadow;
                     if (bo.shadow || lsh) {
                         // trace the shadow ray(s) first; the next bounce ray waits in LDS
@@ -240,7 +239,7 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
                         if (bo.shadow) {
                             lnext = lsh;
                             lkind = false;
-                            const float* job = s_job + lane;     // the sink left the HDRI shadow ray here
+                            // (the hook left the HDRI shadow ray in s_job)
                             trav_begin(T, f3(job[0], job[64], job[128]), f3(job[192], job[256], job[320]), true, __builtin_bit_cast(int, job[384]), job[448]);
                             c_rays++;
                             mode = M_TRACE;

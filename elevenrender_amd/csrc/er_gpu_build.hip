@@ -659,13 +659,13 @@ int er_gpu_build_device(const ErGpuSceneArrays& a, uint32_t n, int device, ErGpu
     GB_OK(hipMemcpyAsync(d_uv.p, a.uvs, (size_t)n * 24, hipMemcpyHostToDevice, st));
     GB_OK(hipMemcpyAsync(d_sign.p, a.tangent_sign, (size_t)n * 4, hipMemcpyHostToDevice, st));
     GB_OK(hipMemcpyAsync(d_mat.p, a.material_id, (size_t)n * 4, hipMemcpyHostToDevice, st));
-    const size_t n8_pieces = (size_t)nodes8_count * 5 + 3;
+    const size_t n8_pieces = (size_t)nodes8_count * ER_NODE8_PIECES + 8;
     const size_t geom_f4 = n8_pieces + ((size_t)n + 1) * 3;
     Dev<float4> d_geom, d_attr;
     GB_OK(hipMalloc(&d_geom.p, geom_f4 * 16));
     GB_OK(hipMalloc(&d_attr.p, (size_t)n * 7 * 16));
     GB_OK(hipMemsetAsync(d_geom.p, 0, n8_pieces * 16, st));
-    GB_OK(hipMemcpyAsync(d_geom.p, d_n8.p, (size_t)nodes8_count * sizeof(ErNode8), hipMemcpyDeviceToDevice, st));
+    GB_OK(hipMemcpy2DAsync(d_geom.p, (size_t)ER_NODE8_PIECES * 16, d_n8.p, sizeof(ErNode8), sizeof(ErNode8), nodes8_count, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_records, dim3((n + 256) / 256), dim3(256), 0, st, d_new_order.p, B.d_ids2.p, n, B.d_v.p, B.d_n.p, d_tan.p, d_uv.p, d_sign.p,
                        d_mat.p, B.d_lift.p, (ErTriIsect*)(d_geom.p + n8_pieces), (ErTriAttr*)d_attr.p, d_s2t.p);
     GB_OK(hipGetLastError());

@@ -31,29 +31,6 @@ __global__ void er_setup_kernel(DevScene S) {
     S.samples[idx] = 1;
 }
 
-// the megakernel's sink (er_shade.h): shadow rays are traced at once through the exact binary-BVH routine
-template <bool COUNT>
-struct MegaSink {
-    const DevScene& S;
-    int* stack;
-    F3& light;
-    F3 &aov_n, &aov_t, &aov_b;
-    unsigned &c_rays, &c_nodes, &c_tris;
-    ERD void hdri_query(const Ray& sr, int self_slot, float d_self, F3 c_vis, F3 c_occ) {
-        float sd;     // occluded iff the closest hit is another triangle (src/kernel.cpp:555-562)
-        c_rays++;
-        const int occ = trace<COUNT, true>(S, stack, sr, self_slot, d_self, sd, c_nodes, c_tris);
-        light = light + (occ >= 0 ? c_occ : c_vis);
-    }
-    ERD void light_query(const Ray& lr, float limit, F3 l_vis, F3 l_occ) {
-        float sd;     // point-light sample (ER_FLAG_POINT_LIGHTS): occluded iff a hit is nearer than the light
-        c_rays++;
-        const int occ = trace<COUNT, true>(S, stack, lr, -1, limit, sd, c_nodes, c_tris);
-        light = light + (occ >= 0 ? l_occ : l_vis);
-    }
-    ERD void first_hit(F3 n, F3 t, F3 b) { aov_n = n; aov_t = t; aov_b = b; }
-};
-
 template <bool COUNT, bool EXT>
 __global__ __launch_bounds__(64) void er_render_kernel(DevScene S, uint32_t n_samples) {
     __shared__ int s_stack[ER_STACK * 64];
@@ -90,11 +67,29 @@ __global__ __launch_bounds__(64) void er_render_kernel(DevScene S, uint32_t n_sa
             float dist;
             c_rays++;
             const int slot = trace<COUNT, false>(S, stack, ray, -1, __builtin_inff(), dist, c_nodes, c_tris);
-            BounceOut o;
-            MegaSink<COUNT> sink{S, stack, light, aov_n, aov_t, aov_b, c_rays, c_nodes, c_tris};
-            bounce_step<COUNT, EXT>(S, ray, slot, rs, light, reduction, bounce, prev_pdf, o, sink, c_shaded, c_texels, c_hdri);
-            ray = o.next;
-            const bool done = o.done;
+            const int hslot = slot;
+            bool done = false, pending = false, lpending = false;
+            // the hooks trace the shadow rays at once through the exact binary-BVH routine and add the selected contribution
+#define ER_BOUNCE_HDRI_QUERY(sr, self_slot, d_self, cv, co)                                                      \
+    {   /* occluded iff the closest hit is another triangle (src/kernel.cpp:555-562) */                           \
+        float sd_;                                                                                                \
+        c_rays++;                                                                                                 \
+        const int occ_ = trace<COUNT, true>(S, stack, (sr), (self_slot), (d_self), sd_, c_nodes, c_tris);         \
+        light = light + (occ_ >= 0 ? (co) : (cv));                                                                \
+    }
+#define ER_BOUNCE_LIGHT_QUERY(lr, limit, lv, lo)                                                                 \
+    {   /* point-light sample (ER_FLAG_POINT_LIGHTS): occluded iff a hit is nearer than the light */              \
+        float sd_;                                                                                                \
+        c_rays++;                                                                                                 \
+        const int occ_ = trace<COUNT, true>(S, stack, (lr), -1, (limit), sd_, c_nodes, c_tris);                   \
+        light = light + (occ_ >= 0 ? (lo) : (lv));                                                                \
+    }
+#define ER_BOUNCE_FIRST_HIT(n, t, b) aov_n = (n); aov_t = (t); aov_b = (b)
+#include "er_bounce.inc"
+#undef ER_BOUNCE_HDRI_QUERY
+#undef ER_BOUNCE_LIGHT_QUERY
+#undef ER_BOUNCE_FIRST_HIT
+            (void)pending; (void)lpending;
             if (done) {
                 sa = accumulate_sample(S, idx, sa, light, aov_n, aov_t, aov_b);   // src/kernel.cpp:597-645
                 c_paths++;

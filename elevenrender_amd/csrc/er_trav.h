@@ -106,7 +106,7 @@ ERD bool trav_choose(Trav& T, const DevScene& S, uint2* stack, uint2* spill, Tra
                 T.sp++;
             }
             T.ng_bits = 0;
-            st.noff = child * 5u;
+            st.noff = child * (uint32_t)ER_NODE8_PIECES;
         }
     }
     return st.tri || st.node;
@@ -269,12 +269,23 @@ ERD float exact_distance(const DevScene& S, uint32_t tslot, const Ray& ray) {
     return candidate_distance(S, tslot, v0, v1, v2, ray, u, v, t);
 }
 
+// The exact scalar re-trace is the rare fallback (more than two candidates inside one t-interval: a handful of rays per
+// million on the test scenes).
+// (Tried out of line, `__attribute__((noinline))`: 40 fewer spilled registers in the shading kernels, but the call takes
+// the DevScene by reference, which pins the kernel-argument struct in scratch memory and turns nearly every load of the
+// kernel into a flat_load -- no faster.  Inline.)
+template <bool COUNT, bool ANY>
+ERD int trace_cold(const DevScene& S, int* stack, const Ray& ray, int skip_slot, float limit, unsigned& node_visits,
+                                                     unsigned& tri_tests) {
+    float dd;
+    return trace<COUNT, ANY>(S, stack, ray, skip_slot, limit, dd, node_visits, tri_tests);
+}
+
 // closest-hit result of a finished traversal: the winning slot (or -1) under the reference's exact metric
 template <bool COUNT>
 ERD int resolve_closest(const DevScene& S, int* stack2, const Ray& ray, int hslot, int h2, unsigned& c_nodes, unsigned& c_tris) {
     if (h2 == -2) {          // more than two candidates inside one t-interval: exact scalar traversal
-        float dd;
-        return trace<COUNT, false>(S, stack2, ray, -1, __builtin_inff(), dd, c_nodes, c_tris);
+        return trace_cold<COUNT, false>(S, stack2, ray, -1, __builtin_inff(), c_nodes, c_tris);
     }
     if (h2 >= 0) {           // two candidates: the reference's strict '<' on the exact metric
         if (exact_distance(S, (uint32_t)h2, ray) < exact_distance(S, (uint32_t)hslot, ray)) return h2;
@@ -286,10 +297,7 @@ ERD int resolve_closest(const DevScene& S, int* stack2, const Ray& ray, int hslo
 template <bool COUNT>
 ERD bool resolve_shadow(const DevScene& S, int* stack2, const Ray& sr, int self_slot, float d_self, int occ, int ca, int cb,
                         unsigned& c_nodes, unsigned& c_tris) {
-    if (occ == 3) {
-        float dd;
-        return trace<COUNT, true>(S, stack2, sr, self_slot, d_self, dd, c_nodes, c_tris) >= 0;
-    }
+    if (occ == 3) return trace_cold<COUNT, true>(S, stack2, sr, self_slot, d_self, c_nodes, c_tris) >= 0;
     if (occ == 2) {
         bool nearer = exact_distance(S, (uint32_t)ca, sr) < d_self;
         if (cb >= 0) nearer = nearer || (exact_distance(S, (uint32_t)cb, sr) < d_self);

@@ -240,36 +240,12 @@ __global__ __launch_bounds__(64, WF_TRACE_WAVES) void er_wf_trace(DevScene S, Wf
 #ifndef WF_SHADE_WAVES
 #define WF_SHADE_WAVES 4
 #endif
-// the wavefront schedule's sink (er_shade.h): queries and AOVs go straight to the slot's records in HBM
-struct WfSink {
-    const WfState& W;
-    uint32_t slot;
-    ERD void hdri_query(const Ray& sr, int self_slot, float d_self, F3 c_vis, F3 c_occ) {
-        W.sh_o[slot] = make_float4(sr.o.x, sr.o.y, sr.o.z, __builtin_bit_cast(float, self_slot));
-        W.sh_d[slot] = make_float4(sr.d.x, sr.d.y, sr.d.z, d_self);
-        W.c_vis[slot] = make_float4(c_vis.x, c_vis.y, c_vis.z, 0.0f);
-        W.c_occ[slot] = make_float4(c_occ.x, c_occ.y, c_occ.z, 0.0f);
-    }
-    ERD void light_query(const Ray& lr, float limit, F3 l_vis, F3 l_occ) {
-        const uint32_t q = slot + W.slots;     // the point-light query of a slot lives in the second half of the records
-        W.sh_o[q] = make_float4(lr.o.x, lr.o.y, lr.o.z, __builtin_bit_cast(float, -1));
-        W.sh_d[q] = make_float4(lr.d.x, lr.d.y, lr.d.z, limit);
-        W.c_vis[q] = make_float4(l_vis.x, l_vis.y, l_vis.z, 0.0f);
-        W.c_occ[q] = make_float4(l_occ.x, l_occ.y, l_occ.z, 0.0f);
-    }
-    ERD void first_hit(F3 n, F3 t, F3 b) {
-        W.aov_n[slot] = make_float4(n.x, n.y, n.z, 0.0f);
-        W.aov_t[slot] = make_float4(t.x, t.y, t.z, 0.0f);
-        W.aov_b[slot] = make_float4(b.x, b.y, b.z, 0.0f);
-    }
-};
-
 template <bool COUNT, bool EXT>
 __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, WfState W, uint32_t parity) {
     __shared__ int s_stack[ER_STACK * 64];   // only for the rare exact re-trace of an overflowed ray
     // queue entries are staged per wave and appended WF_STAGE tickets at a time: the two queue-length words are
     // single addresses, and one address takes ~90 atomics/us whatever the number of waves
-    __shared__ uint32_t s_qc[WF_STAGE * 64], s_qs[WF_STAGE * 64];   // (a ticket stages <= 64 closest and <= 128 shadow entries)
+    __shared__ uint32_t s_qc[WF_STAGE * 64], s_qs[WF_STAGE * 64];
     unsigned n_qc = 0, n_qs = 0;             // staged entries (wave-uniform)
     const int lane = threadIdx.x;
     int* stack = s_stack + lane;
@@ -280,6 +256,7 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
     const uint32_t* qc = W.q[parity];
     uint32_t* qn = W.q[parity ^ 1];
     uint32_t* qsn = W.qs[parity ^ 1];
+    const size_t npx = (size_t)S.x_res * S.y_res;
     unsigned c_paths = 0, c_bounce = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;
     // tickets (64 slots each) are taken several at a time: one atomic per chunk
     uint32_t tchunk = wC / (gridDim.x * 4u);
@@ -294,7 +271,7 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
             t_end = base + tchunk < wC ? base + tchunk : wC;
             if (base >= wC) break;
         }
-        if (n_qc > (WF_STAGE - 1) * 64 || n_qs > (WF_STAGE - 2) * 64) {   // no room for another ticket: append
+        if (n_qc > (WF_STAGE - 1) * 64 || n_qs > (WF_STAGE - (EXT ? 2 : 1)) * 64) {   // no room for another ticket: append
             __syncthreads();
             queue_flush(&W.counts[WF_NC + WF_PAR(parity ^ 1)], qn, s_qc, n_qc);
             queue_flush(&W.counts[WF_NS + WF_PAR(parity ^ 1)], qsn, s_qs, n_qs);
@@ -318,22 +295,38 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
             uint32_t rs = __builtin_bit_cast(uint32_t, L4.w);
             uint32_t packed = __builtin_bit_cast(uint32_t, R4.w);
             uint32_t bounce = packed & 0xFFFFu;
-            // resolve the previous bounce's shadow queries, in the order of the additions: HDRI term, then point light
-#pragma unroll
-            for (int kind = 0; kind < (EXT ? 2 : 1); kind++) {
-                if (packed & (kind ? WF_LPENDING : WF_PENDING)) {
-                    const uint32_t q = slot + (kind ? W.slots : 0u);     // light queries live in the second half
-                    int occ = W.occluded[q];
-                    if (occ >= 2) {          // the trace kernel could not decide from t-intervals: exact metric
-                        float4 so = W.sh_o[q], sd = W.sh_d[q];
-                        Ray sr;
-                        sr.o = f3(so.x, so.y, so.z);
-                        sr.d = f3(sd.x, sd.y, sd.z);
-                        occ = resolve_shadow<COUNT>(S, stack, sr, __builtin_bit_cast(int, so.w), sd.w, occ, W.occ_a[q], W.occ_b[q], c_nodes, c_tris) ? 1 : 0;
+            if (packed & WF_PENDING) {   // resolve the previous bounce's shadow query
+                int occ = W.occluded[slot];
+                if (occ >= 2) {          // the trace kernel could not decide from t-intervals: exact metric
+                    float4 so = W.sh_o[slot], sd = W.sh_d[slot];
+                    Ray sr;
+                    sr.o = f3(so.x, so.y, so.z);
+                    sr.d = f3(sd.x, sd.y, sd.z);
+                    if (occ == 3) {
+                        float dd;
+                        occ = trace<COUNT, true>(S, stack, sr, __builtin_bit_cast(int, so.w), sd.w, dd, c_nodes, c_tris) >= 0 ? 1 : 0;
+                    } else {
+                        int ca = W.occ_a[slot], cb = W.occ_b[slot];
+                        bool nearer = exact_distance(S, (uint32_t)ca, sr) < sd.w;
+                        if (cb >= 0) nearer = nearer || (exact_distance(S, (uint32_t)cb, sr) < sd.w);
+                        occ = nearer ? 1 : 0;
                     }
-                    float4 c = occ ? W.c_occ[q] : W.c_vis[q];
-                    light = light + f3(c.x, c.y, c.z);
                 }
+                float4 c = occ ? W.c_occ[slot] : W.c_vis[slot];
+                light = light + f3(c.x, c.y, c.z);
+            }
+            if (EXT && (packed & WF_LPENDING)) {   // ... then its point-light query (second half of the shadow records)
+                const uint32_t q = slot + W.slots;
+                int occ = W.occluded[q];
+                if (occ >= 2) {
+                    float4 so = W.sh_o[q], sd = W.sh_d[q];
+                    Ray sr;
+                    sr.o = f3(so.x, so.y, so.z);
+                    sr.d = f3(sd.x, sd.y, sd.z);
+                    occ = resolve_shadow<COUNT>(S, stack, sr, __builtin_bit_cast(int, so.w), sd.w, occ, W.occ_a[q], W.occ_b[q], c_nodes, c_tris) ? 1 : 0;
+                }
+                float4 c = occ ? W.c_occ[q] : W.c_vis[q];
+                light = light + f3(c.x, c.y, c.z);
             }
             bool pending = false, lpending = false;
             bool done = fin_only;
@@ -343,27 +336,64 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
                 float4 o = W.ray_o[slot], d = W.ray_d[slot];
                 ray.o = f3(o.x, o.y, o.z);
                 ray.d = f3(d.x, d.y, d.z);
-                if (EXT) prev_pdf = d.w;
-                const int hslot = resolve_closest<COUNT>(S, stack, ray, W.hit[slot], W.hit2[slot], c_nodes, c_tris);
+                int hslot = W.hit[slot];
+                int h2 = W.hit2[slot];
+                if (h2 == -2) {          // more than two candidates inside one t-interval: exact scalar traversal
+                    float dd;
+                    hslot = trace<COUNT, false>(S, stack, ray, -1, __builtin_inff(), dd, c_nodes, c_tris);
+                } else if (h2 >= 0) {    // two candidates: the reference's strict '<' on the exact metric
+                    if (exact_distance(S, (uint32_t)h2, ray) < exact_distance(S, (uint32_t)hslot, ray)) hslot = h2;
+                }
                 c_bounce++;
-                BounceOut bo;
-                WfSink sink{W, slot};
-                bounce_step<COUNT, EXT>(S, ray, hslot, rs, light, reduction, bounce, prev_pdf, bo, sink, c_shaded, c_texels, c_hdri);
-                pending = bo.shadow;
-                lpending = EXT && bo.lshadow;
-                ray = bo.next;
-                done = bo.done;
+                if (EXT) prev_pdf = d.w;
+#define ER_BOUNCE_HDRI_QUERY(sr, self_slot, d_self, cv, co)                                                     \
+    W.sh_o[slot] = make_float4((sr).o.x, (sr).o.y, (sr).o.z, __builtin_bit_cast(float, (int)(self_slot)));      \
+    W.sh_d[slot] = make_float4((sr).d.x, (sr).d.y, (sr).d.z, (d_self));                                          \
+    W.c_vis[slot] = make_float4((cv).x, (cv).y, (cv).z, 0.0f);                                                   \
+    W.c_occ[slot] = make_float4((co).x, (co).y, (co).z, 0.0f)
+#define ER_BOUNCE_LIGHT_QUERY(lr, limit, lv, lo)                                                                \
+    {   /* the point-light query of a slot lives in the second half of the shadow records */                    \
+        const uint32_t lq = slot + W.slots;                                                                      \
+        const F3 lv_ = (lv), lo_ = (lo);                                                                         \
+        W.sh_o[lq] = make_float4((lr).o.x, (lr).o.y, (lr).o.z, __builtin_bit_cast(float, -1));                   \
+        W.sh_d[lq] = make_float4((lr).d.x, (lr).d.y, (lr).d.z, (limit));                                         \
+        W.c_vis[lq] = make_float4(lv_.x, lv_.y, lv_.z, 0.0f);                                                    \
+        W.c_occ[lq] = make_float4(lo_.x, lo_.y, lo_.z, 0.0f);                                                    \
+    }
+#define ER_BOUNCE_FIRST_HIT(n, t, b)                                                                            \
+    W.aov_n[slot] = make_float4((n).x, (n).y, (n).z, 0.0f);                                                      \
+    W.aov_t[slot] = make_float4((t).x, (t).y, (t).z, 0.0f);                                                      \
+    W.aov_b[slot] = make_float4((b).x, (b).y, (b).z, 0.0f)
+#include "er_bounce.inc"
+#undef ER_BOUNCE_HDRI_QUERY
+#undef ER_BOUNCE_LIGHT_QUERY
+#undef ER_BOUNCE_FIRST_HIT
             }
             bool alive = true;
             if (done && (pending || lpending)) {
-                // the path is over but its last shadow queries are in flight: come back once, without a ray
+                // the path is over but its last shadow query is in flight: come back once, without a ray
                 next_entry = slot | ER_WF_FINALIZE_ONLY;
                 push_closest = true;
             } else if (done) {
-                float4 an = W.aov_n[slot], at = W.aov_t[slot], ab = W.aov_b[slot];
-                const uint32_t sa = S.samples[idx];
-                const uint32_t sa2 = accumulate_sample(S, idx, sa, light, f3(an.x, an.y, an.z), f3(at.x, at.y, at.z), f3(ab.x, ab.y, ab.z));
-                if (sa2 != sa) S.samples[idx] = sa2;
+                // src/kernel.cpp:597-645
+                light = f3(clampf(light.x, 0, 10), clampf(light.y, 0, 10), clampf(light.z, 0, 10));
+                uint32_t sa = S.samples[idx];
+                if (!(light.x != light.x) && !(light.y != light.y) && !(light.z != light.z)) {
+                    float k = ((float)sa) / ((float)(sa + 1));
+                    float inv = (float)(sa + 1);
+                    float4 an = W.aov_n[slot], at = W.aov_t[slot], ab = W.aov_b[slot];
+                    const F3 vals[4] = {light, f3(an.x, an.y, an.z), f3(at.x, at.y, at.z), f3(ab.x, ab.y, ab.z)};
+                    const int planes[4] = {ER_PASS_BEAUTY, ER_PASS_NORMAL, ER_PASS_TANGENT, ER_PASS_BITANGENT};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        float4* pp = S.passes + (size_t)planes[q] * npx + idx;
+                        float4 p = *pp;
+                        if (sa > 0) { p.x *= k; p.y *= k; p.z *= k; }
+                        p.x += vals[q].x / inv; p.y += vals[q].y / inv; p.z += vals[q].z / inv;
+                        *pp = p;
+                    }
+                    S.samples[idx] = sa + 1;
+                }
                 S.rng[idx] = rs;
                 c_paths++;
                 uint32_t left = W.left[slot] - 1;
@@ -388,24 +418,25 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
                 push_closest = true;
             }
             push_shadow = pending;
-            push_light = lpending;
+            push_light = EXT && lpending;
             if (alive) {
                 if (!(next_entry & ER_WF_FINALIZE_ONLY)) {
                     W.ray_o[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
-                    W.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, prev_pdf);
+                    W.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, EXT ? prev_pdf : -1.0f);
                 }
                 W.light[slot] = make_float4(light.x, light.y, light.z, __builtin_bit_cast(float, rs));
                 W.reduc[slot] = make_float4(reduction.x, reduction.y, reduction.z,
-                                            __builtin_bit_cast(float, bounce | (pending ? WF_PENDING : 0u) | (lpending ? WF_LPENDING : 0u)));
+                                            __builtin_bit_cast(float, bounce | (pending ? WF_PENDING : 0u) | ((EXT && lpending) ? WF_LPENDING : 0u)));
             }
         }
-        const unsigned long long mc = __ballot(push_closest), ms = __ballot(push_shadow), ml = __ballot(push_light);
+        const unsigned long long mc = __ballot(push_closest), ms = __ballot(push_shadow);
         const unsigned long long below = (1ull << lane) - 1ull;
         if (push_closest) s_qc[n_qc + __popcll(mc & below)] = next_entry;
         if (push_shadow) s_qs[n_qs + __popcll(ms & below)] = slot;
         n_qc += __popcll(mc);
         n_qs += __popcll(ms);
-        if (EXT && ml) {   // point-light queries (ER_FLAG_POINT_LIGHTS): entry = slot + slots, the second half of the shadow records
+        if (EXT) {   // point-light queries (ER_FLAG_POINT_LIGHTS): entry = slot + slots, the second half of the shadow records
+            const unsigned long long ml = __ballot(push_light);
             if (push_light) s_qs[n_qs + __popcll(ml & below)] = slot + W.slots;
             n_qs += __popcll(ml);
         }
@@ -423,6 +454,7 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
         if (COUNT) atomicAdd(&S.counters->texel_fetches, (unsigned long long)t7);
     }
 }
+
 
 hipError_t er_probe_wavefront(const char** which) {
     hipFuncAttributes a;
