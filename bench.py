@@ -261,15 +261,12 @@ def main():
             # er_gather_pass = pack -> ncclSend / ncclRecv over xGMI -> unpack.  If the C++ path cannot start on this
             # node (RCCL not loadable ...) every rank falls back to the torch.distributed gather so that the line is
             # not lost; `gather` says which path ran.
-            ok = torch.ones(1, dtype=torch.int32, device="cuda")
             comm = None
             try:
-                comm = erdist.NativeComm(dist, rank, world, local_rank)
+                comm = erdist.NativeComm(dist, rank, world, local_rank)   # (the ranks agree inside before anything collective)
             except Exception as e:
-                print(f"[rank {rank}] er_comm_create failed: {e}", file=sys.stderr)
-                ok.zero_()
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 1:
+                print(f"[rank {rank}] native RCCL communicator not available: {e}", file=sys.stderr)
+            if comm is not None:
                 for p in range(abi.PASS_COUNT):
                     comm.gather_pass(rm, p)
                 gather_path = "er_gather_pass (RCCL from the C++ side, 5 planes)"

@@ -126,6 +126,9 @@ SYMBOLS = {
     "er_accel_info": (C.c_int, [_P, C.POINTER(ErAccelInfo)]),
     "er_get_profile": (C.c_int, [_P, C.POINTER(ErProfile)]),
     "er_denoise": (C.c_int, [_P, C.c_uint32, C.c_float]),
+    "er_state_size": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "er_state_export": (C.c_int, [_P, _P, C.c_uint64]),
+    "er_state_import": (C.c_int, [_P, _P, C.c_uint64]),
     "er_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
     "er_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32, C.c_int, C.POINTER(_P)]),
     "er_comm_destroy": (None, [_P]),

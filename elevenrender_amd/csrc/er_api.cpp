@@ -579,6 +579,73 @@ static int er_read_pass_impl(ErScene* s, int pass, float* dst) {
     size_t npx = (size_t)s->x_res * s->y_res;
     return read_back(s, s->d_passes.p + (size_t)pass * npx, dst, npx * sizeof(float4), "er_read_pass");
 }
+// ---- checkpoint / resume: passes + samples + rng are the whole progressive state (reference src/kernel.h:44-46) ----
+namespace {
+struct StateHeader {
+    char magic[8];            // "ERSTATE1"
+    uint32_t x_res, y_res, passes, reserved;
+    uint64_t bytes;
+    uint8_t pad[32];
+};
+static_assert(sizeof(StateHeader) == 64, "snapshot header is 64 bytes");
+uint64_t state_bytes(const ErScene* s) {
+    const uint64_t npx = (uint64_t)s->x_res * s->y_res;
+    return sizeof(StateHeader) + npx * (ER_PASS_COUNT * sizeof(float4) + 2 * sizeof(uint32_t));
+}
+}  // namespace
+
+static int er_state_size_impl(ErScene* s, uint64_t* bytes) {
+    if (!s || !bytes) return fail(ER_ERR_INVALID_ARG, "er_state_size: NULL argument");
+    *bytes = state_bytes(s);
+    return ER_OK;
+}
+
+static int er_state_export_impl(ErScene* s, void* dst, uint64_t bytes) {
+    if (!s || !dst) return fail(ER_ERR_INVALID_ARG, "er_state_export: NULL argument");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if (!s->begun) return fail(ER_ERR_STATE, "er_state_export: er_render_begin has not succeeded");
+    if (bytes < state_bytes(s)) return fail(ER_ERR_INVALID_ARG, "er_state_export: buffer smaller than er_state_size");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t npx = (size_t)s->x_res * s->y_res;
+    StateHeader h{};
+    memcpy(h.magic, "ERSTATE1", 8);
+    h.x_res = s->x_res; h.y_res = s->y_res; h.passes = ER_PASS_COUNT; h.bytes = state_bytes(s);
+    uint8_t* p = (uint8_t*)dst;
+    memcpy(p, &h, sizeof(h));
+    p += sizeof(h);
+    // ordered after everything enqueued so far (the pool streams join the scene's stream at the end of every call)
+    HIP_TRY(hipMemcpyAsync(p, s->d_passes.p, npx * ER_PASS_COUNT * sizeof(float4), hipMemcpyDeviceToHost, s->stream));
+    p += npx * ER_PASS_COUNT * sizeof(float4);
+    HIP_TRY(hipMemcpyAsync(p, s->d_samples.p, npx * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    p += npx * sizeof(uint32_t);
+    HIP_TRY(hipMemcpyAsync(p, s->d_rng.p, npx * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return ER_OK;
+}
+
+static int er_state_import_impl(ErScene* s, const void* src, uint64_t bytes) {
+    if (!s || !src) return fail(ER_ERR_INVALID_ARG, "er_state_import: NULL argument");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if (!s->begun) return fail(ER_ERR_STATE, "er_state_import: er_render_begin has not succeeded");
+    StateHeader h;
+    if (bytes < sizeof(h)) return fail(ER_ERR_INVALID_ARG, "er_state_import: truncated snapshot");
+    memcpy(&h, src, sizeof(h));
+    if (memcmp(h.magic, "ERSTATE1", 8) != 0) return fail(ER_ERR_INVALID_ARG, "er_state_import: not a snapshot (bad magic)");
+    if (h.x_res != s->x_res || h.y_res != s->y_res || h.passes != ER_PASS_COUNT)
+        return fail(ER_ERR_INVALID_ARG, "er_state_import: the snapshot is of a " + std::to_string(h.x_res) + "x" + std::to_string(h.y_res) + " frame");
+    if (h.bytes != state_bytes(s) || bytes < h.bytes) return fail(ER_ERR_INVALID_ARG, "er_state_import: truncated snapshot");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t npx = (size_t)s->x_res * s->y_res;
+    const uint8_t* p = (const uint8_t*)src + sizeof(h);
+    HIP_TRY(hipMemcpyAsync(s->d_passes.p, p, npx * ER_PASS_COUNT * sizeof(float4), hipMemcpyHostToDevice, s->stream));
+    p += npx * ER_PASS_COUNT * sizeof(float4);
+    HIP_TRY(hipMemcpyAsync(s->d_samples.p, p, npx * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    p += npx * sizeof(uint32_t);
+    HIP_TRY(hipMemcpyAsync(s->d_rng.p, p, npx * sizeof(uint32_t), hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));      // the caller's buffer may go away
+    return ER_OK;
+}
+
 static int er_denoise_impl(ErScene* s, uint32_t levels, float colour_sigma) {
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_denoise: NULL scene");
     std::lock_guard<std::mutex> lk(s->mtx);
@@ -700,6 +767,9 @@ int er_wait(ErScene* s, float* elapsed_ms) { return guarded("er_wait", [&]() -> 
 int er_render_samples(ErScene* s, uint32_t n) { return guarded("er_render_samples", [&]() -> int { return er_render_samples_impl(s, n); }); }
 int er_samples_done(ErScene* s, uint32_t* out) { return guarded("er_samples_done", [&]() -> int { return er_samples_done_impl(s, out); }); }
 int er_read_pass(ErScene* s, int pass, float* dst) { return guarded("er_read_pass", [&]() -> int { return er_read_pass_impl(s, pass, dst); }); }
+int er_state_size(ErScene* s, uint64_t* bytes) { return guarded("er_state_size", [&]() -> int { return er_state_size_impl(s, bytes); }); }
+int er_state_export(ErScene* s, void* dst, uint64_t bytes) { return guarded("er_state_export", [&]() -> int { return er_state_export_impl(s, dst, bytes); }); }
+int er_state_import(ErScene* s, const void* src, uint64_t bytes) { return guarded("er_state_import", [&]() -> int { return er_state_import_impl(s, src, bytes); }); }
 int er_denoise(ErScene* s, uint32_t levels, float colour_sigma) { return guarded("er_denoise", [&]() -> int { return er_denoise_impl(s, levels, colour_sigma); }); }
 int er_read_samples(ErScene* s, uint32_t* dst) { return guarded("er_read_samples", [&]() -> int { return er_read_samples_impl(s, dst); }); }
 int er_read_rng(ErScene* s, uint32_t* dst) { return guarded("er_read_rng", [&]() -> int { return er_read_rng_impl(s, dst); }); }

@@ -99,15 +99,23 @@ class NativeComm:
         import torch
         from . import abi
         self.lib = abi.load()
+        self.handle = C.c_void_p()
+        on_gpu = dist.get_backend() == "nccl"
+        dev = "cuda" if on_gpu else "cpu"
+        # 1. every rank checks locally that RCCL can be loaded at all (er_comm_unique_id dlopens it); the ranks agree
+        #    BEFORE anybody enters the collective ncclCommInitRank, so that a rank without RCCL cannot strand the others
         ident = (C.c_uint8 * 128)()
-        if rank == 0:
-            abi.check(self.lib.er_comm_unique_id(ident))
-        t = torch.tensor(list(ident), dtype=torch.uint8)
-        if dist.get_backend() == "nccl":
-            t = t.cuda()
+        rc = self.lib.er_comm_unique_id(ident)
+        ok = torch.tensor([1 if rc == abi.ER_OK else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            raise abi.ErError(rc if rc != abi.ER_OK else abi.ER_ERR_NO_DEVICE,
+                              "er_comm_unique_id failed on at least one rank: " + self.lib.er_last_error().decode("utf-8", "replace"))
+        # 2. rank 0's id travels through the host's channel (every other rank's probe id is discarded)
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=dev)
         dist.broadcast(t, src=0)
         ident = (C.c_uint8 * 128)(*t.cpu().tolist())
-        self.handle = C.c_void_p()
+        # 3. collective: ncclCommInitRank on every rank
         abi.check(self.lib.er_comm_create(ident, rank, world, device, C.byref(self.handle)))
 
     def gather_pass(self, rm, pass_id, root=0):

@@ -178,6 +178,18 @@ class RenderingManager:
         abi.check(self.lib.er_debug_trace_pixel(self.handle, idx, recs, max_recs, C.byref(n)))
         return [recs[i] for i in range(n.value)]
 
+    def state_export(self):
+        """er_state_export: the whole progressive state (planes + sample counts + RNG) as bytes."""
+        n = C.c_uint64()
+        abi.check(self.lib.er_state_size(self.handle, C.byref(n)))
+        buf = np.empty(n.value, np.uint8)
+        abi.check(self.lib.er_state_export(self.handle, buf.ctypes.data_as(C.c_void_p), n.value))
+        return buf
+
+    def state_import(self, buf):
+        b = np.ascontiguousarray(buf, np.uint8)
+        abi.check(self.lib.er_state_import(self.handle, b.ctypes.data_as(C.c_void_p), b.size))
+
     def owned_count(self, rank):
         v = C.c_uint64()
         abi.check(self.lib.er_owned_count(self.handle, rank, C.byref(v)))

@@ -189,6 +189,17 @@ int er_samples_done(ErScene* scene, uint32_t* out);
 int er_read_pass(ErScene* scene, int pass, float* dst_rgba);
 int er_read_samples(ErScene* scene, uint32_t* dst);
 
+/* Checkpoint / resume (the reference keeps the progressive estimator only in device memory --
+ * dev_passes + dev_samples + dev_randstate, src/kernel.h:44-46 -- and these three arrays ARE a complete resumable state).
+ * er_state_size: bytes of one snapshot of this scene (5 planes of float4 + 2 u32 per pixel + a 64-byte header).
+ * er_state_export: a sample-boundary snapshot into host memory (ordered after everything enqueued, like er_read_pass).
+ * er_state_import: after er_render_begin on a scene of the same resolution, continue from a snapshot: the next
+ * er_render_samples(n) gives exactly what n more samples would have given in the run that exported it (per-pixel RNG
+ * streams; any schedule, any rank/world split -- a rank only ever touches the pixels it owns). */
+int er_state_size(ErScene* scene, uint64_t* bytes);
+int er_state_export(ErScene* scene, void* dst, uint64_t bytes);
+int er_state_import(ErScene* scene, const void* src, uint64_t bytes);
+
 /* Fills the DENOISE plane (which renderingKernel never writes, src/kernel.cpp:604) with an edge-avoiding a-trous
  * wavelet filter of the current BEAUTY plane, guided by colour and by the NORMAL plane: `levels` passes (1..8, 0 -> 5)
  * with stencil holes of 1, 2, 4, ... pixels; colour_sigma > 0 scales the colour edge-stop (0 -> 1).  Stands in for the

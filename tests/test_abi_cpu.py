@@ -61,6 +61,9 @@ def test_argument_validation_and_error_text():
     assert lib.er_render_samples(h, 1) == abi.ER_ERR_STATE
     assert lib.er_read_pass(h, 0, buf.ctypes.data_as(C.POINTER(C.c_float))) == abi.ER_ERR_STATE
     assert lib.er_read_pass(h, 7, buf.ctypes.data_as(C.POINTER(C.c_float))) == abi.ER_ERR_INVALID_ARG
+    n = C.c_uint64()
+    assert lib.er_state_size(h, C.byref(n)) == abi.ER_OK and n.value == 64 + 16 * 16 * (5 * 16 + 8)
+    assert lib.er_state_export(h, buf.ctypes.data_as(C.c_void_p), n.value) == abi.ER_ERR_STATE
     p = abi.ErRenderParams(16, 8, 5, 0, 3, 2, 0)          # rank >= world
     assert lib.er_render_begin(h, C.byref(p)) == abi.ER_ERR_INVALID_ARG
     lib.er_scene_destroy(h)

@@ -68,3 +68,38 @@ def test_rccl_transport_initialises_and_a_one_rank_gather_is_a_no_op():
     assert lib.er_gather_pass(rm.handle, abi.PASS_BEAUTY, comm, 3) == abi.ER_ERR_INVALID_ARG
     rm.close()
     lib.er_comm_destroy(comm)
+
+
+def test_native_communicator_beside_torch_distributed_rccl():
+    """bench.py --gpus N creates the library's RCCL communicator in a process where torch.distributed's "nccl" backend
+    (PyTorch's own RCCL) is already initialised; only the 128-byte id goes through torch.  Rehearsed here with one rank:
+    both RCCL users coexist, the id broadcast works on the GPU, the gather is a no-op."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from elevenrender_amd import dist as erdist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)                                   # PyTorch's RCCL is live
+        comm = erdist.NativeComm(dist, 0, 1, 0)
+        rm = render.RenderingManager(render.RenderParameters())
+        rm.start_rendering(scenes.cornell(32, 24))
+        rm.render(2)
+        before = rm.get_pass("beauty")
+        for p in range(abi.PASS_COUNT):
+            comm.gather_pass(rm, p)
+        assert (rm.get_pass("beauty").view(np.uint32) == before.view(np.uint32)).all()
+        comm.close()
+        rm.close()
+        dist.all_reduce(t)                                   # ... and still is
+        assert float(t[0]) == 1.0
+    finally:
+        dist.destroy_process_group()
