@@ -135,6 +135,7 @@ SYMBOLS = {
     "er_gather_pass": (C.c_int, [_P, C.c_int, _P, C.c_uint32]),
     "er_debug_comm_create_local": (C.c_int, [C.c_uint32, C.POINTER(_P)]),
     "er_measure_hbm_peak": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, _FP, _FP]),
+    "er_debug_eval": (C.c_int, [_P, C.c_int, _FP, C.c_uint32, C.c_uint32, _FP, C.c_uint32]),
     "er_debug_trace_rays": (C.c_int, [_P, _FP, _FP, C.c_uint32, _IP, _FP, _IP, _IP, _FP, _FP, _IP]),
     "er_debug_trace_pixel": (C.c_int, [_P, C.c_uint32, C.POINTER(ErTraceRec), C.c_int, C.POINTER(C.c_int)]),
     "er_debug_set_host_alloc_limit": (None, [C.c_uint64]),

@@ -15,6 +15,8 @@ void er_launch_debug_trace(const DevScene& S, const float* o, const float* d, ui
 // ONE more sample of pixel idx, one record per executed bounce-loop iteration.  spill: ER_DEBUG_PIXEL_SCRATCH uint2.
 #define ER_DEBUG_PIXEL_SCRATCH ((32 + 8 + 16) * 64)   /* spill levels + LDS-stack levels + the exact routine's int stack */
 void er_launch_debug_pixel(const DevScene& S, uint32_t idx, ErTraceRec* recs, int max_recs, int* count, void* spill, hipStream_t stream);
+// device functions of the path, one item per thread (ER_FN_* of include/eleven_hip_debug.h)
+void er_launch_debug_eval(const DevScene& S, int kind, const float* in, uint32_t n, uint32_t in_stride, float* out, uint32_t out_stride, hipStream_t stream);
 // streaming kernels for the measured HBM peak: copy (dst = src) and triad-like read-modify-write over n float4.
 void er_launch_hbm_copy(const float4* src, float4* dst, size_t n, hipStream_t stream);
 void er_launch_hbm_read(const float4* src, float* sink, size_t n, hipStream_t stream);

@@ -146,6 +146,110 @@ void er_launch_debug_pixel(const DevScene& S, uint32_t idx, ErTraceRec* recs, in
     else hipLaunchKernelGGL(er_debug_pixel_kernel<false>, dim3(1), dim3(64), 0, stream, S, idx, recs, max_recs, count, (uint2*)spill);
 }
 
+// ---- the device functions of the path, one item per thread (known-answer tests against the oracle's entry points) ----
+namespace {
+ERD HitData hd_from(const float* h) {     // the oracle's hd[20] layout
+    HitData d;
+    d.metallic = h[0]; d.roughness = h[1]; d.clearcoatGloss = h[2]; d.clearcoat = h[3]; d.anisotropic = h[4];
+    d.transmission = h[5]; d.specular = h[6]; d.specularTint = h[7]; d.sheenTint = h[8]; d.subsurface = h[9];
+    d.sheen = h[10]; d.opacity = 1.0f;
+    d.albedo = f3(h[11], h[12], h[13]); d.tangent = f3(h[14], h[15], h[16]); d.bitangent = f3(h[17], h[18], h[19]);
+    d.emission = f3s(0); d.position = f3s(0); d.normal = f3s(0);
+    return d;
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void er_debug_eval_kernel(DevScene S, int kind, const float* __restrict__ in, uint32_t n, uint32_t in_stride,
+                                                           float* __restrict__ out, uint32_t out_stride) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float* a = in + (size_t)i * in_stride;
+    float* o = out + (size_t)i * out_stride;
+    auto bits = [](float f) { return __builtin_bit_cast(int, f); };
+    auto fbits = [](uint32_t u) { return __builtin_bit_cast(float, u); };
+    switch (kind) {
+        case ER_FN_RNG: {
+            uint32_t st = jenkins_u32((uint32_t)bits(a[0]) + 1u);      // RngGenerator(idx), src/kernel.cpp:38-40,183
+            for (int k = 0; k < 16; k++) { o[k] = rng_next(st); o[16 + k] = fbits(st); }
+            break;
+        }
+        case ER_FN_CAMERA_RAY: {
+            const Ray r = camera_ray(S.cam, (int)a[0], (int)a[1], S.x_res, S.y_res, a[2], a[3], a[4], a[5], a[6]);
+            o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+            break;
+        }
+        case ER_FN_TRI_HIT: {
+            const int id = bits(a[0]);
+            int slot = -1;
+            for (uint32_t s = 0; s < S.tri_count; s++)
+                if (__builtin_bit_cast(int, S.tri_isect[(size_t)s * 3].w) == id) { slot = (int)s; break; }
+            Ray ray;
+            ray.o = f3(a[1], a[2], a[3]);
+            ray.d = f3(a[4], a[5], a[6]);
+            for (int k = 0; k < 18; k++) o[k] = 0.0f;
+            if (slot < 0) break;
+            F3 v0, v1, v2;
+            float4 qa, qb, qc;
+            load_verts(S, (uint32_t)slot, v0, v1, v2, qa, qb, qc);
+            float u, v, t;
+            if (!tri_mt(v0, v1, v2, ray, u, v, t)) break;
+            HitFull h;
+            full_hit(S, (uint32_t)slot, ray, h);
+            o[0] = 1.0f;
+            const F3 vs[5] = {h.position, h.normal, h.gnormal, h.tangent, h.bitangent};
+            for (int k = 0; k < 5; k++) { o[1 + 3 * k] = vs[k].x; o[2 + 3 * k] = vs[k].y; o[3 + 3 * k] = vs[k].z; }
+            o[16] = h.tu; o[17] = h.tv;
+            break;
+        }
+        case ER_FN_DISNEY_EVAL: {
+            const F3 r = DisneyEval(hd_from(a), f3(a[20], a[21], a[22]), f3(a[23], a[24], a[25]), f3(a[26], a[27], a[28]));
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            break;
+        }
+        case ER_FN_DISNEY_PDF:
+            o[0] = DisneyPdf(hd_from(a), f3(a[20], a[21], a[22]), f3(a[23], a[24], a[25]), f3(a[26], a[27], a[28]));
+            break;
+        case ER_FN_DISNEY_SAMPLE: {
+            const F3 r = DisneySample(hd_from(a), f3(a[20], a[21], a[22]), f3(a[23], a[24], a[25]), a[26], a[27], a[28]);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            break;
+        }
+        case ER_FN_SPHERICAL:
+            spherical_mapping(f3(a[0], a[1], a[2]), o[0], o[1]);
+            break;
+        case ER_FN_REV_SPHERICAL: {
+            const F3 r = reverse_spherical_mapping(a[0], a[1]);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            break;
+        }
+        case ER_FN_TEXTURE: {
+            const int id = bits(a[0]);
+            const DevTex t = id < 0 ? S.hdri_tex : S.textures[id];
+            const F3 r = a[3] != 0.0f ? tex_filtered(S, t, a[1], a[2]) : tex_uv(S, t, a[1], a[2]);
+            o[0] = r.x; o[1] = r.y; o[2] = r.z;
+            break;
+        }
+        case ER_FN_HDRI_SEARCH:
+            o[0] = fbits((uint32_t)er_cdf_search(S.hdri_cdf, S.hdri_tex.width * S.hdri_tex.height, S.hdri_guide, S.hdri_buckets, a[0]));
+            break;
+        case ER_FN_HDRI_PDF:
+            o[0] = hdri_pdf(S, bits(a[0]), bits(a[1]));
+            break;
+        case ER_FN_MATH: {
+            const int op = bits(a[0]);
+            const float x = a[1], y = a[2];
+            o[0] = op == 0 ? ermath::er_sin(x) : op == 1 ? ermath::er_cos(x) : op == 2 ? ermath::er_acos(x) : op == 3 ? ermath::er_log(x)
+                 : op == 4 ? ermath::er_pow(x, y) : ermath::er_atan2(x, y);
+            break;
+        }
+        default: break;
+    }
+}
+void er_launch_debug_eval(const DevScene& S, int kind, const float* in, uint32_t n, uint32_t in_stride, float* out, uint32_t out_stride, hipStream_t stream) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(er_debug_eval_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, S, kind, in, n, in_stride, out, out_stride);
+}
+
 // ---- streaming kernels for the measured HBM peak ("measured peak from a device-to-device copy / triad
 // kernel run in the same job").  Grid-stride over float4, 4 independent 16-byte accesses in flight per lane. ----
 typedef float VF4 __attribute__((ext_vector_type(4)));

@@ -174,6 +174,33 @@ static int er_debug_trace_pixel_impl(ErScene* s, uint32_t idx, ErTraceRec* recs,
     return ER_OK;
 }
 
+static int er_debug_eval_impl(ErScene* s, int kind, const float* in, uint32_t n, uint32_t in_stride, float* out, uint32_t out_stride) {
+    static const uint32_t need_in[ER_FN_COUNT] = {1, 7, 7, 29, 29, 29, 3, 2, 4, 1, 2, 3};
+    static const uint32_t need_out[ER_FN_COUNT] = {32, 6, 18, 3, 1, 3, 2, 3, 3, 1, 1, 1};
+    if (!s || !in || !out) return fail(ER_ERR_INVALID_ARG, "er_debug_eval: NULL argument");
+    if (kind < 0 || kind >= ER_FN_COUNT) return fail(ER_ERR_INVALID_ARG, "er_debug_eval: unknown kind");
+    if (in_stride < need_in[kind] || out_stride < need_out[kind]) return fail(ER_ERR_INVALID_ARG, "er_debug_eval: stride smaller than the kind's item");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if (!s->begun) return fail(ER_ERR_STATE, "er_debug_eval: er_render_begin has not succeeded");
+    if (kind == ER_FN_TEXTURE)
+        for (uint32_t i = 0; i < n; i++) {
+            int32_t id;
+            memcpy(&id, &in[(size_t)i * in_stride], 4);
+            if (id < -1 || id >= (int32_t)s->textures.size()) return fail(ER_ERR_INVALID_ARG, "er_debug_eval: texture id out of range");
+        }
+    HIP_TRY(hipSetDevice(s->device));
+    ScopedDevBuf<float> d_in, d_out;
+    int rc;
+    if ((rc = upload(d_in, in, (size_t)n * in_stride, s->stream)) != ER_OK) return rc;
+    if ((rc = upload(d_out, (const float*)nullptr, (size_t)n * out_stride, s->stream)) != ER_OK) return rc;
+    HIP_TRY(hipMemsetAsync(d_out.p, 0, std::max<size_t>((size_t)n * out_stride, 1) * sizeof(float), s->stream));
+    er_launch_debug_eval(s->dev, kind, d_in.p, n, in_stride, d_out.p, out_stride, s->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, d_out.p, (size_t)n * out_stride * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return ER_OK;
+}
+
 static int er_measure_hbm_peak_impl(int device, uint64_t bytes, uint32_t iters, float* copy_GBps, float* read_GBps) {
     if (!copy_GBps || !read_GBps) return fail(ER_ERR_INVALID_ARG, "er_measure_hbm_peak: NULL argument");
     int ndev = er_device_count();
@@ -231,6 +258,9 @@ int er_debug_trace_rays(ErScene* s, const float* origins, const float* dirs, uin
 }
 int er_debug_trace_pixel(ErScene* s, uint32_t idx, ErTraceRec* recs, int max_recs, int* count) {
     return guarded("er_debug_trace_pixel", [&]() -> int { return er_debug_trace_pixel_impl(s, idx, recs, max_recs, count); });
+}
+int er_debug_eval(ErScene* s, int kind, const float* in, uint32_t n, uint32_t in_stride, float* out, uint32_t out_stride) {
+    return guarded("er_debug_eval", [&]() -> int { return er_debug_eval_impl(s, kind, in, n, in_stride, out, out_stride); });
 }
 int er_measure_hbm_peak(int device, uint64_t bytes, uint32_t iters, float* copy_GBps, float* read_GBps) {
     return guarded("er_measure_hbm_peak", [&]() -> int { return er_measure_hbm_peak_impl(device, bytes, iters, copy_GBps, read_GBps); });

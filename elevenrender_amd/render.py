@@ -171,6 +171,15 @@ class RenderingManager:
         abi.check(self.lib.er_debug_trace_rays(self.handle, fp(o), fp(d), n, ip(ss), fp(lim), ip(tri), ip(slot), fp(pos), fp(dist), ip(info)))
         return tri.astype(bool), info
 
+    def debug_eval(self, kind, items, out_width):
+        """include/eleven_hip_debug.h er_debug_eval: one DEVICE function of the path per row of `items` ([n, in_width] float32;
+        integer inputs as float bits).  Returns [n, out_width] float32."""
+        a = np.ascontiguousarray(items, np.float32)
+        out = np.zeros((a.shape[0], out_width), np.float32)
+        fp = lambda x: x.ctypes.data_as(C.POINTER(C.c_float))
+        abi.check(self.lib.er_debug_eval(self.handle, kind, fp(a), a.shape[0], a.shape[1], fp(out), out_width))
+        return out
+
     def debug_trace_pixel(self, idx, max_recs=64):
         """include/eleven_hip_debug.h: one more sample of pixel idx, one ErTraceRec per bounce-loop iteration."""
         recs = (abi.ErTraceRec * max_recs)()

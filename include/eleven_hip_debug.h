@@ -68,6 +68,30 @@ typedef struct ErTraceRec {
  * er_render_samples(scene, 1) restricted to that pixel.  *count = records written. */
 int er_debug_trace_pixel(struct ErScene* scene, uint32_t idx, ErTraceRec* recs, int max_recs, int* count);
 
+/* The DEVICE functions of the path, one call per item, for known-answer tests against the oracle's function-level entry
+ * points (SURVEY.md section 4 level 1: a1 RNG, a3 camera, a5 Tri::hit record, a6-a8 textures and mappings, a9 HDRI search /
+ * pdf, a10-a12 Disney sample / eval / pdf, the transcendentals).  `in` holds n items of in_stride floats, `out` receives n
+ * items of out_stride floats (integers travel as float BITS).  Needs a scene on which er_render_begin has succeeded (the
+ * camera, textures, HDRI and triangles are the scene's).  Kinds and layouts:
+ *   ER_FN_RNG            in [bits(pixel idx)]                          out [16 x next(), 16 x bits(state)]        (32)
+ *   ER_FN_CAMERA_RAY     in [x, y, r1, r2, r3, r4, r5]                 out [origin(3), dir(3)]                    (6)
+ *   ER_FN_TRI_HIT        in [bits(original tri id), origin(3), dir(3)] out [valid, position(3), normal(3), gnormal(3),
+ *                                                                           tangent(3), bitangent(3), tu, tv]     (18)
+ *   ER_FN_DISNEY_EVAL    in [hd(20), V(3), N(3), L(3)]                 out [rgb]                                  (3)
+ *   ER_FN_DISNEY_PDF     in [hd(20), V(3), N(3), L(3)]                 out [pdf]                                  (1)
+ *   ER_FN_DISNEY_SAMPLE  in [hd(20), V(3), N(3), r1, r2, r3]           out [dir(3)]                               (3)
+ *     hd = metallic, roughness, clearcoatGloss, clearcoat, anisotropic, transmission, specular, specularTint, sheenTint,
+ *          subsurface, sheen, albedo(3), tangent(3), bitangent(3)   -- the oracle's layout (oracle/er_oracle.h)
+ *   ER_FN_SPHERICAL      in [p(3)]                                     out [u, v]                                 (2)
+ *   ER_FN_REV_SPHERICAL  in [u, v]                                     out [p(3)]                                 (3)
+ *   ER_FN_TEXTURE        in [bits(texture id, -1 = the HDRI), u, v, filtered(0/1)]   out [rgb]                    (3)
+ *   ER_FN_HDRI_SEARCH    in [value]                                    out [bits(index)]                          (1)
+ *   ER_FN_HDRI_PDF       in [bits(x), bits(y)]                         out [pdf]                                  (1)
+ *   ER_FN_MATH           in [bits(op: 0 sin 1 cos 2 acos 3 log 4 pow 5 atan2), x, y]   out [value]                (1) */
+enum { ER_FN_RNG = 0, ER_FN_CAMERA_RAY, ER_FN_TRI_HIT, ER_FN_DISNEY_EVAL, ER_FN_DISNEY_PDF, ER_FN_DISNEY_SAMPLE, ER_FN_SPHERICAL,
+       ER_FN_REV_SPHERICAL, ER_FN_TEXTURE, ER_FN_HDRI_SEARCH, ER_FN_HDRI_PDF, ER_FN_MATH, ER_FN_COUNT };
+int er_debug_eval(struct ErScene* scene, int kind, const float* in, uint32_t n, uint32_t in_stride, float* out, uint32_t out_stride);
+
 /* Loopback transport for er_gather_pass: `world` communicators that live in ONE process and move the packed buffers
  * through device-to-device copies, so that pack -> exchange -> unpack can be driven on a one-GPU box without RCCL (which
  * refuses two ranks on one GPU).  out[world].  Call er_gather_pass for the non-root ranks first, then for the root. */
