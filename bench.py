@@ -378,7 +378,14 @@ def main():
                          "region_ms": round(kernel_ms, 3),
                          "whole_path_GBps": round(path_b / wall_s / 1e9, 2),
                          "node_visits_per_ray": round(ci["node_visits"] / max(1, ci["rays"]), 2),
-                         "tri_tests_per_ray": round(ci["tri_tests"] / max(1, ci["rays"]), 2)},
+                         "tri_tests_per_ray": round(ci["tri_tests"] / max(1, ci["rays"]), 2),
+                         # lane occupancy of er_wf_trace's loop in the instrumented replay: share of the 64 lanes that held a
+                         # ray / ran the node part / ran the triangle part, per loop iteration of a wave
+                         "trace_lanes": None if not ci.get("trace_wave_steps") else {
+                             "wave_steps": ci["trace_wave_steps"],
+                             "busy": round(ci["trace_busy_lanes"] / (64.0 * ci["trace_wave_steps"]), 4),
+                             "node": round(ci["trace_node_lanes"] / (64.0 * ci["trace_wave_steps"]), 4),
+                             "tri": round(ci["trace_tri_lanes"] / (64.0 * ci["trace_wave_steps"]), 4)}},
             "accel": {"nodes": accel["node_count"], "node_bytes": accel["node_bytes"], "leaves": accel["leaf_count"],
                       "max_depth": accel["max_depth"], "build_ms": round(accel["build_ms"], 1), "builder": "device linear BVH" if accel["builder"] else "host binned SAH", "upload_ms": round(accel["upload_ms"], 2)},
             "readback_ms": round(readback_ms, 2), "gather": gather_path, "beauty_mean": beauty_mean,

@@ -80,7 +80,8 @@ class ErDeviceInfo(C.Structure):
 
 class ErCounters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("paths", "bounce_samples", "rays", "node_visits", "tri_tests",
-                                          "shaded_hits", "texel_fetches", "hdri_samples")]
+                                          "shaded_hits", "texel_fetches", "hdri_samples", "trace_wave_steps", "trace_busy_lanes",
+                                          "trace_node_lanes", "trace_tri_lanes")]
 
 
 class ErProfile(C.Structure):

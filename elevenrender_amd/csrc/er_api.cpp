@@ -737,6 +737,8 @@ static int er_get_counters_impl(ErScene* s, ErCounters* out) {
     out->paths = c.paths; out->bounce_samples = c.bounce_samples; out->rays = c.rays; out->node_visits = c.node_visits;
     out->tri_tests = c.tri_tests; out->shaded_hits = c.shaded_hits; out->texel_fetches = c.texel_fetches;
     out->hdri_samples = c.hdri_samples;
+    out->trace_wave_steps = c.trace_wave_steps; out->trace_busy_lanes = c.trace_busy_lanes;
+    out->trace_node_lanes = c.trace_node_lanes; out->trace_tri_lanes = c.trace_tri_lanes;
     return ER_OK;
 }
 

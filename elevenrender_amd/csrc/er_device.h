@@ -24,6 +24,7 @@ struct DevTex {
 
 struct DevCounters {
     unsigned long long paths, bounce_samples, rays, node_visits, tri_tests, shaded_hits, texel_fetches, hdri_samples;
+    unsigned long long trace_wave_steps, trace_busy_lanes, trace_node_lanes, trace_tri_lanes;
 };
 
 struct DevScene {

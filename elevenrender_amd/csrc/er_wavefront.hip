@@ -124,6 +124,7 @@ __global__ __launch_bounds__(64, WF_TRACE_WAVES) void er_wf_trace(DevScene S, Wf
     const uint32_t* qc = W.q[parity];
     const uint32_t* qs = W.qs[parity];
     unsigned c_rays = 0, c_nodes = 0, c_tris = 0;
+    unsigned c_wsteps = 0, c_busy = 0, c_nl = 0, c_tl = 0;   // ER_FLAG_COUNTERS: lane occupancy of this loop (wave-uniform)
 
     Trav T;
     trav_begin(T, f3s(0), f3(0, 0, 1), false, -1, 0.0f);
@@ -197,8 +198,25 @@ __global__ __launch_bounds__(64, WF_TRACE_WAVES) void er_wf_trace(DevScene S, Wf
         TravStep st;
         st.node = false; st.tri = false; st.two = false; st.tslot = 0; st.noff = 0; st.toff = 0;
         if (busy) { do_step = trav_choose(T, S, stack, spill, st); finished = !do_step; }
+        if (COUNT) {
+            c_wsteps++;
+            c_busy += (unsigned)__popcll(__ballot(busy));
+            c_nl += (unsigned)__popcll(__ballot(st.node));
+            c_tl += (unsigned)__popcll(__ballot(st.tri));
+        }
         TravData D;
         trav_fetch(S, st, D);
+#if defined(ER_TRACE_PAD_VALU)   // diagnostic builds (tools/ab_pad.sh): what is a step bound by?  N extra dependent VALU operations ...
+        {
+            float pad = T.U;
+#pragma unroll
+            for (int k = 0; k < ER_TRACE_PAD_VALU; k++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pad));
+            asm volatile("" ::"v"(pad));
+        }
+#endif
+#if defined(ER_TRACE_PAD_SLEEP)  // ... or N x 64 idle cycles of this wave per step (issue slots stay free for the other waves)
+        __builtin_amdgcn_s_sleep(ER_TRACE_PAD_SLEEP);
+#endif
         if (busy) {
             if (do_step) {
                 if (trav_apply<COUNT>(T, S, st, D, c_nodes, c_tris)) {
@@ -228,6 +246,10 @@ __global__ __launch_bounds__(64, WF_TRACE_WAVES) void er_wf_trace(DevScene S, Wf
         if (COUNT) {
             atomicAdd(&S.counters->node_visits, (unsigned long long)t1);
             atomicAdd(&S.counters->tri_tests, (unsigned long long)t2);
+            atomicAdd(&S.counters->trace_wave_steps, (unsigned long long)c_wsteps);
+            atomicAdd(&S.counters->trace_busy_lanes, (unsigned long long)c_busy);
+            atomicAdd(&S.counters->trace_node_lanes, (unsigned long long)c_nl);
+            atomicAdd(&S.counters->trace_tri_lanes, (unsigned long long)c_tl);
         }
     }
 }

@@ -155,6 +155,9 @@ typedef struct ErCounters {
     uint64_t shaded_hits;      /* closest hits shaded */
     uint64_t texel_fetches;    /* only with ER_FLAG_COUNTERS */
     uint64_t hdri_samples;     /* CDF searches */
+    /* lane occupancy of the wavefront traversal loop (only with ER_FLAG_COUNTERS): iterations of er_wf_trace's loop summed
+     * over its waves, and how many of the 64 lanes held a ray / ran the node part / ran the triangle part in them */
+    uint64_t trace_wave_steps, trace_busy_lanes, trace_node_lanes, trace_tri_lanes;
 } ErCounters;
 
 typedef struct ErScene ErScene;   /* opaque */

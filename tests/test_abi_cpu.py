@@ -37,7 +37,7 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(abi.ErCamera) == 5 * 4 + 12 + 4 + 12
     assert C.sizeof(abi.ErMaterial) == 8 * 4 + 24 + 15 * 4
     assert C.sizeof(abi.ErTexture) == 24
-    assert C.sizeof(abi.ErCounters) == 64
+    assert C.sizeof(abi.ErCounters) == 96
     assert C.sizeof(abi.ErRenderParams) == 28
 
 
