@@ -152,8 +152,8 @@ def make_scene(args, scenes, abi):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="C2", help="BASELINE.json scene (default C2, the one the metric is quoted on)")
     ap.add_argument("--tris", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=0)

@@ -421,6 +421,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
         HIP_TRY(hipEventRecord(s->ev_start, s->stream));
         s->timing_open = true;
     }
+    if (n > 0) for (auto& u : s->unpacked) u.clear();     // other ranks' pixels gathered earlier are stale from here on
     const bool count = (s->params.flags & ER_FLAG_COUNTERS) != 0;
     const bool single = (s->params.flags & (ER_FLAG_FUSED | ER_FLAG_MEGAKERNEL)) != 0;
     if (single && (s->params.flags & ER_FLAG_PROFILE) && n > 0) {
@@ -650,7 +651,10 @@ static int er_denoise_impl(ErScene* s, uint32_t levels, float colour_sigma) {
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_denoise: NULL scene");
     std::lock_guard<std::mutex> lk(s->mtx);
     if (!s->begun) return fail(ER_ERR_STATE, "er_denoise: er_render_begin has not succeeded");
-    if (s->params.world > 1) return fail(ER_ERR_STATE, "er_denoise: the frame is sharded over several ranks; gather it first");
+    // a sharded frame: only on the rank that BEAUTY and NORMAL were gathered to (er_gather_pass / er_unpack_owned of every
+    // other rank) after the last sample; DenoiseManager of the reference likewise runs where the whole pass is (src/CommandManager.cpp:265-274)
+    if (s->params.world > 1 && (s->unpacked[ER_PASS_BEAUTY].size() + 1 < s->params.world || s->unpacked[ER_PASS_NORMAL].size() + 1 < s->params.world))
+        return fail(ER_ERR_STATE, "er_denoise: the frame is sharded over several ranks; gather BEAUTY and NORMAL to this rank first (er_gather_pass)");
     if (levels == 0) levels = 5;
     if (levels > 8) return fail(ER_ERR_INVALID_ARG, "er_denoise: at most 8 levels");
     if (!(colour_sigma >= 0)) return fail(ER_ERR_INVALID_ARG, "er_denoise: colour_sigma must be >= 0");
@@ -726,6 +730,7 @@ static int er_unpack_owned_impl(ErScene* s, int pass, uint32_t src_rank, const v
     er_launch_unpack(s->dev, it->second.p, (uint32_t)it->second.n, pass, dev_src, s->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (src_rank != s->params.rank) s->unpacked[pass].insert(src_rank);
     return ER_OK;
 }
 

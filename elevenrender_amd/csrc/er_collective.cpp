@@ -236,6 +236,7 @@ static int er_gather_pass_impl(ErScene* s, int pass, ErComm* c, uint32_t root) {
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t r = 0; r < c->world; r++) if (r != root) s->unpacked[pass].insert(r);
     return ER_OK;
 }
 

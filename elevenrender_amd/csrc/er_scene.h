@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -188,6 +189,9 @@ struct ErScene {
     size_t prof_used = 0;
     ErProfile profile{};
     std::map<uint32_t, DevBuf<uint32_t>> d_rank_tiles;   // tile lists of other ranks (for unpack)
+    // which ranks' pixels of each plane were unpacked into this scene since the last sample was enqueued: er_denoise on a
+    // sharded frame needs the whole BEAUTY and NORMAL planes (the rank the frame was gathered to)
+    std::set<uint32_t> unpacked[ER_PASS_COUNT];
     std::mutex mtx;
 
     std::vector<uint32_t> tiles_of(uint32_t rank, uint32_t world) const {

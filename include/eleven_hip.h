@@ -207,7 +207,9 @@ int er_state_import(ErScene* scene, const void* src, uint64_t bytes);
  * wavelet filter of the current BEAUTY plane, guided by colour and by the NORMAL plane: `levels` passes (1..8, 0 -> 5)
  * with stencil holes of 1, 2, 4, ... pixels; colour_sigma > 0 scales the colour edge-stop (0 -> 1).  Stands in for the
  * reference's host-side OIDN call behind `get_pass denoise` (src/Managers.cpp:319-343, CommandManager.cpp:265-274) --
- * a different filter: no parity claim.  Single-GPU (world 1) only. */
+ * a different filter: no parity claim.  On a frame sharded over several ranks (world > 1) it runs on the rank that BEAUTY
+ * and NORMAL have been gathered to since the last sample (er_gather_pass, or er_unpack_owned of every other rank), as
+ * the reference denoises where the whole pass is; elsewhere ER_ERR_STATE. */
 int er_denoise(ErScene* scene, uint32_t levels, float colour_sigma);     /* x_res*y_res */
 int er_read_rng(ErScene* scene, uint32_t* dst);         /* x_res*y_res */
 

@@ -22,6 +22,12 @@ def test_gather_pass_over_the_loopback_transport_reassembles_the_frame(sched):
     lib = abi.load()
     sc = scenes.soup(5000, 100, 76, seed=9, hdri_size=(64, 32))     # 100x76: partial tiles on both edges
     full = gpu_render(sc, 5, max_bounces=8, flags=sched)
+    one = render.RenderingManager(render.RenderParameters(max_bounces=8, flags=sched))   # the single-GPU frame, denoised
+    one.start_rendering(sc)
+    one.render(5)
+    one.denoise()
+    full_denoised = one.get_pass("denoise")
+    one.close()
     world, root = 3, 1                                              # a root that is not rank 0
     comms = (C.c_void_p * world)()
     abi.check(lib.er_debug_comm_create_local(world, comms))
@@ -31,12 +37,19 @@ def test_gather_pass_over_the_loopback_transport_reassembles_the_frame(sched):
         rm.start_rendering(sc)
         rm.render(5, blocking=False)            # no wait: the gather is ordered after the samples on the scene's stream
         rms.append(rm)
+    # denoising a sharded frame needs the whole BEAUTY and NORMAL planes: refused until they have been gathered
+    assert lib.er_denoise(rms[root].handle, 0, 0.0) == abi.ER_ERR_STATE
+    assert b"gather BEAUTY and NORMAL" in lib.er_last_error()
     for p in range(abi.PASS_COUNT):
         for r in [x for x in range(world) if x != root] + [root]:
             abi.check(lib.er_gather_pass(rms[r].handle, p, comms[r], root))
     for name, p in abi.PASS_NAMES.items():
         got = rms[root].get_pass(name)
         assert (got.view(np.uint32) == full[name].view(np.uint32)).all(), name
+    # ... then the root denoises the gathered frame exactly as one GPU would its own; the other ranks still cannot
+    rms[root].denoise()
+    assert (rms[root].get_pass("denoise").view(np.uint32) == full_denoised.view(np.uint32)).all()
+    assert lib.er_denoise(rms[0].handle, 0, 0.0) == abi.ER_ERR_STATE
     # a non-root rank still holds only its own pixels
     other = rms[0].get_pass("beauty")
     assert (other.view(np.uint32) != full["beauty"].view(np.uint32)).any()
