@@ -165,7 +165,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's all-core leg (0 = every core this job may use)")
     ap.add_argument("--no-trace-phase", action="store_true", help="skip the single-pool pass that measures the traversal phase alone")
     ap.add_argument("--per-step-launch", action="store_true", help="one launch per step instead of one launch for all K steps")
-    ap.add_argument("--schedule", choices=["auto", "wavefront", "fused", "megakernel"], default="auto")
+    ap.add_argument("--schedule", choices=["auto", "wavefront", "fused", "megakernel", "stream"], default="auto")
     ap.add_argument("--gpu-build", action="store_true", help="build the BVH on the GPU (ER_FLAG_GPU_BUILD) instead of the host SAH build")
     ap.add_argument("--sim-world", type=int, default=0, help="(diagnostic) render only rank --sim-rank's tiles of this many, no collective")
     ap.add_argument("--sim-rank", type=int, default=0)
@@ -201,7 +201,7 @@ def main():
 
     scene, ext_flags, workload = make_scene(args, scenes, abi)
     shard_rank, shard_world = (args.sim_rank, args.sim_world) if (args.sim_world > 1 and world == 1) else (rank, world)
-    sched_flag = {"auto": 0, "wavefront": abi.FLAG_WAVEFRONT, "fused": abi.FLAG_FUSED, "megakernel": abi.FLAG_MEGAKERNEL}[args.schedule]
+    sched_flag = {"auto": 0, "wavefront": abi.FLAG_WAVEFRONT, "fused": abi.FLAG_FUSED, "megakernel": abi.FLAG_MEGAKERNEL, "stream": abi.FLAG_STREAM}[args.schedule]
     base_flags = sched_flag | ext_flags | (abi.FLAG_GPU_BUILD if args.gpu_build else 0)
 
     def manager(extra_flags):
@@ -300,7 +300,7 @@ def main():
         path_b = path_bytes(ci, hdri_texels) / max(1, ci["bounce_samples"]) * my_samples
         t_launches = max(1, prof["trace_launches"])
         trace_ms_avg = prof["trace_ms"] / t_launches
-        sched = {abi.FLAG_WAVEFRONT: "wavefront", abi.FLAG_FUSED: "fused", abi.FLAG_MEGAKERNEL: "megakernel"}.get(prof["schedule"], "?")
+        sched = {abi.FLAG_WAVEFRONT: "wavefront", abi.FLAG_FUSED: "fused", abi.FLAG_MEGAKERNEL: "megakernel", abi.FLAG_STREAM: "stream"}.get(prof["schedule"], "?")
         kernel_name = {"wavefront": "er_wf_trace", "fused": "er_fused_kernel", "megakernel": "er_render_kernel"}.get(sched, "?")
         if sched != "wavefront":
             layout_b = path_b + (layout_b - trace_b)

@@ -274,11 +274,11 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, sizeof(DevCounters), s->stream));
     // schedule: forced by a flag, else by how many pixels this rank owns (see eleven_hip.h)
     {
-        const uint32_t forced = p->flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT);
+        const uint32_t forced = p->flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM);
         uint32_t sched = forced;
         if (forced == 0) sched = (owned.size() * 64 > 1200000u) ? ER_FLAG_WAVEFRONT : ER_FLAG_FUSED;
         else if (forced & (forced - 1)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: more than one schedule flag");
-        s->params.flags = (s->params.flags & ~(uint32_t)(ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT)) | sched;
+        s->params.flags = (s->params.flags & ~(uint32_t)(ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM)) | sched;
     }
     if (s->params.flags & ER_FLAG_FUSED) {
         hipDeviceProp_t prop;
@@ -289,6 +289,34 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         if ((rc = upload(s->d_spill, nullptr, (size_t)s->fused_blocks * ER_BVH_MAX_DEPTH * 64 * 3 / 2, s->stream)) != ER_OK) return rc;
         // per-wave rings of (slot, samples left) records: capacity ceil(chunks / waves) * 4 each
         if ((rc = upload(s->d_ticket, nullptr, (owned.size() * 64 + 4 * (size_t)s->fused_blocks) * 2, s->stream)) != ER_OK) return rc;
+    } else if (s->params.flags & ER_FLAG_STREAM) {
+        // streaming schedule: one workgroup per CU with ER_STREAM_SLOTS slots of the wavefront schedule's records each
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, s->device));
+        s->stream_blocks = (uint32_t)prop.multiProcessorCount;
+        s->stream_tracers = 10;
+        if (const char* e = getenv("ER_STREAM_TRACERS")) s->stream_tracers = (uint32_t)std::min(12, std::max(1, atoi(e)));   // tuning knob
+        const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
+        const size_t sh = lights_on ? 2 : 1;
+        if ((rc = upload(s->d_wf4, nullptr, slots * (7 + 4 * sh), s->stream)) != ER_OK) return rc;
+        if ((rc = upload(s->d_wf1, nullptr, slots * (4 + 3 * sh) + 2, s->stream)) != ER_OK) return rc;
+        if ((rc = upload(s->d_spill, nullptr, (size_t)s->stream_blocks * 16 * ER_BVH_MAX_DEPTH * 64, s->stream)) != ER_OK) return rc;
+        WfState W{};
+        float4* f = s->d_wf4.p;
+        W.ray_o = f; W.ray_d = f + slots; W.light = f + 2 * slots; W.reduc = f + 3 * slots;
+        W.aov_n = f + 4 * slots; W.aov_t = f + 5 * slots; W.aov_b = f + 6 * slots;
+        W.sh_o = f + 7 * slots; W.sh_d = W.sh_o + sh * slots; W.c_vis = W.sh_d + sh * slots; W.c_occ = W.c_vis + sh * slots;
+        uint32_t* u = s->d_wf1.p;
+        W.hit = (int*)u; W.left = u + slots; W.hit2 = (int*)(u + 2 * slots);
+        W.occluded = (int*)(u + 3 * slots); W.occ_a = W.occluded + sh * slots; W.occ_b = W.occ_a + sh * slots;
+        s->stream_pix = u + (3 + 3 * sh) * slots;
+        s->stream_ctl = s->stream_pix + slots;             // [0] pixel ticket, [1] status
+        HIP_TRY(hipMemsetAsync(s->stream_ctl, 0, 2 * sizeof(uint32_t), s->stream));
+        W.spill = s->d_spill.p;
+        W.slots = (uint32_t)slots;
+        W.pool = 0; W.pools = 1;
+        s->wf.clear();
+        s->wf.push_back(W);
     } else if (s->params.flags & ER_FLAG_WAVEFRONT) {
         // wavefront path state: one slot per owned pixel lane.
         // SLOT POOLS: the owned tiles are dealt round-robin to `pools` independent path pools, each with its own
@@ -423,7 +451,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     }
     if (n > 0) for (auto& u : s->unpacked) u.clear();     // other ranks' pixels gathered earlier are stale from here on
     const bool count = (s->params.flags & ER_FLAG_COUNTERS) != 0;
-    const bool single = (s->params.flags & (ER_FLAG_FUSED | ER_FLAG_MEGAKERNEL)) != 0;
+    const bool single = (s->params.flags & (ER_FLAG_FUSED | ER_FLAG_MEGAKERNEL | ER_FLAG_STREAM)) != 0;
     if (single && (s->params.flags & ER_FLAG_PROFILE) && n > 0) {
         while (s->prof_events.size() < s->prof_used + 3) {
             hipEvent_t e;
@@ -434,6 +462,8 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     }
     if (s->params.flags & ER_FLAG_FUSED) {
         er_launch_fused(s->dev, s->d_ticket.p, s->d_spill.p, n, count, s->fused_blocks, s->stream);
+    } else if (s->params.flags & ER_FLAG_STREAM) {
+        er_launch_stream(s->dev, s->wf[0], s->stream_pix, s->stream_ctl, s->stream_ctl + 1, n, count, s->stream_blocks, s->stream_tracers, s->stream);
     } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
         er_launch_render(s->dev, n, count, s->stream);
     }
@@ -510,7 +540,7 @@ static int er_wait_impl(ErScene* s, float* elapsed_ms) {
     }
     if (elapsed_ms) *elapsed_ms = ms;
     s->profile = ErProfile{};
-    s->profile.schedule = s->params.flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT);
+    s->profile.schedule = s->params.flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM);
     s->profile.concurrency = (s->params.flags & ER_FLAG_WAVEFRONT) ? (uint32_t)std::max<size_t>(1, s->wf.size()) : 1u;
     // The wavefront host loop always enqueues n * (max_bounces + 1) iterations per pool; the last ones find empty
     // queues (a path rarely takes every bounce).  Those launches are reported apart, so that per-launch figures are

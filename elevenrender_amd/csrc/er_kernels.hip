@@ -8,6 +8,7 @@
 // starts its next sample immediately ("path regeneration"), so wavefronts stay full
 // until a lane has finished all n samples instead of idling to the longest path.
 #include "er_kernels.h"
+#include "er_stream.h"
 #include "er_device.h"
 #include "er_shade.h"
 
@@ -173,6 +174,7 @@ hipError_t er_probe_kernels(const char** which) {
     if ((e = hipFuncGetAttributes(&a, (const void*)er_render_kernel<false, false>)) != hipSuccess) return e;
     if ((e = er_probe_wavefront(which)) != hipSuccess) return e;
     if ((e = er_probe_fused(which)) != hipSuccess) return e;
+    if ((e = er_probe_stream(which)) != hipSuccess) return e;
     if ((e = er_probe_gpu_build(which)) != hipSuccess) return e;
     *which = nullptr;
     return hipSuccess;

@@ -1,0 +1,515 @@
+// er_stream.hip -- CU-resident streaming schedule of the per-sample path for gfx950 (ER_FLAG_STREAM).
+//
+// Same arithmetic per pixel as renderingKernel (reference src/kernel.cpp:477-646) and as the other schedules of this
+// library; the per-slot records are those of the wavefront schedule (er_wavefront.h) and the traversal step and the bounce
+// step are the shared ones (er_trav.h, er_bounce.inc).  What changes is, once more, only the schedule:
+//
+//   * ONE launch per call; one workgroup of 16 waves per CU, resident for the whole call.  The first `tracers` waves only
+//     trace, the others only shade (the split is a launch argument);
+//   * a workgroup owns ST_SLOTS slots.  A slot holds one pixel at a time: it runs that pixel's samples one after the other
+//     (one RNG stream) and then takes the next pixel from a global ticket; its state lives in HBM exactly as in the
+//     wavefront schedule, but it is only ever touched by waves of its own workgroup -- i.e. of one CU, which share the
+//     vector L1 -- so workgroup-scope release/acquire (a wait for the wave's own stores) is all the ordering needed;
+//   * the two kinds of waves feed each other through two rings in LDS: rays to trace (closest-hit and shadow queries) and
+//     slots to shade.  A per-slot counter in LDS holds the number of rays of the slot still in flight; the tracer that
+//     finishes the last one appends the slot to the shade ring.  A consumer LANE reserves a ring position (one LDS atomic
+//     per wave and iteration) and polls that cell until a producer has filled it, so a ring never has to be "non-empty"
+//     for a reservation to succeed and no lane waits for another lane's ray;
+//   * there is no launch boundary between bounces and therefore no tail in which a few long rays hold a launch open: a
+//     tracer lane that finishes a ray takes the next one from the ring, whatever bounce or sample it belongs to.
+//
+// Every wave leaves its loop when the workgroup's last slot has retired (s_ctl[C_DONE]); a wave that sees no progress for
+// ~0.2 s raises the status word and ends the workgroup (it cannot hang).
+#include <cstdlib>
+#include "er_device.h"
+#include "er_kernels.h"
+#include "er_wavefront.h"
+#include "er_trav.h"
+#include "er_shade.h"
+#include "er_stream.h"
+
+using namespace erd;
+
+namespace {
+
+// ring capacities (powers of two).  ray ring: >= 3 rays per slot (2 without the point-light extension) + one reservation per
+// tracer lane; shade ring: >= one entry per slot + one reservation per shader lane
+#define ST_POW2_GE(x) ((x) <= 1024u ? 1024u : (x) <= 2048u ? 2048u : (x) <= 4096u ? 4096u : (x) <= 8192u ? 8192u : 16384u)
+#define ST_RQ_CAP_OF(ext) ST_POW2_GE(((ext) ? 3u : 2u) * ER_STREAM_SLOTS + 768u)
+#define ST_SQ_CAP ST_POW2_GE(ER_STREAM_SLOTS + 1024u)
+#define ST_KIND_SHIFT 13         // ray-ring entry = local slot | kind << 12: 0 closest hit, 1 HDRI shadow query, 2 point-light query
+#define ST_FIN 0x100u            // s_wait flag: when its rays are done the slot is only finalised (ER_WF_FINALIZE_ONLY)
+#define ST_SQ_FIN 0x10000u       // the same flag in a shade-ring entry
+#define ST_NONE 0xFFFFFFFFu
+#define ST_MAX_TRACERS 12
+enum { C_RQ_HEAD = 0, C_RQ_TAIL, C_SQ_HEAD, C_SQ_TAIL, C_LIVE, C_DONE, C_WORDS };
+#define ST_WATCHDOG 1500000u     // idle polls (>= 128 cycles each) without any ring activity in the workgroup before a wave gives up
+#define WF_PENDING_BIT 0x10000u  // per-slot flags in reduc.w, as in er_wavefront.hip: bounce (bits 0-15) | pending HDRI shadow query
+#define WF_LPENDING_BIT 0x20000u //   | pending point-light query
+
+__device__ __forceinline__ unsigned st_wave_sum(unsigned v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// wave-aggregated reservation of ring positions (LDS counter): returns this lane's position (valid only if `want`)
+__device__ __forceinline__ uint32_t st_reserve(uint32_t* counter, bool want) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0) return 0;
+    const unsigned lane = threadIdx.x & 63;
+    const unsigned leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// the next owned pixel for every lane that wants one (global ticket over the owned tiles, 64 pixels each; pixels of border
+// tiles that fall outside the image are skipped).  All lanes of the wave call.
+__device__ __forceinline__ bool st_take_pixel(const DevScene& S, uint32_t* ticket, bool want, uint32_t& px, uint32_t& py) {
+    const uint32_t total = S.owned_tile_count * 64u;
+    bool got = false;
+    while (true) {
+        const unsigned long long m = __ballot(want && !got);
+        if (m == 0) break;
+        const unsigned lane = threadIdx.x & 63;
+        const unsigned leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(ticket, (uint32_t)__popcll(m));
+        base = __shfl(base, leader, 64);
+        if (base >= total) break;
+        if (want && !got) {
+            const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (k < total) {
+                const uint32_t tile = S.owned_tiles[k >> 6], l = k & 63u;
+                px = (tile % S.tiles_x) * ER_TILE + (l & 7u);
+                py = (tile / S.tiles_x) * ER_TILE + (l >> 3);
+                got = px < S.x_res && py < S.y_res;
+            }
+        }
+    }
+    return got;
+}
+
+}  // namespace
+
+template <bool COUNT, bool EXT>
+__global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, WfState W, uint32_t* pix, uint32_t* ticket, uint32_t* status,
+                                                          uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min) {
+    __shared__ uint2 s_stack[ST_MAX_TRACERS * WF_LDS_STACK * 64];
+    constexpr uint32_t ST_RQ_CAP = ST_RQ_CAP_OF(EXT);
+    __shared__ uint32_t s_rq[ST_RQ_CAP];
+    __shared__ uint32_t s_sq[ST_SQ_CAP];
+    __shared__ uint32_t s_wait[ER_STREAM_SLOTS];
+    __shared__ uint32_t s_ctl[C_WORDS];
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t g0 = blockIdx.x * ER_STREAM_SLOTS;          // this workgroup's first slot
+    volatile uint32_t* v_rq = s_rq;
+    volatile uint32_t* v_sq = s_sq;
+    volatile uint32_t* v_ctl = s_ctl;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    // ---- start: empty rings, then every slot takes a pixel and queues its first camera ray ----
+    for (uint32_t i = threadIdx.x; i < ST_RQ_CAP; i += 1024) s_rq[i] = 0;
+    for (uint32_t i = threadIdx.x; i < ST_SQ_CAP; i += 1024) s_sq[i] = 0;
+    if (threadIdx.x < C_WORDS) s_ctl[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < ER_STREAM_SLOTS; s += 1024) {
+        uint32_t px = 0, py = 0;
+        const bool got = st_take_pixel(S, ticket, n_samples > 0, px, py);
+        s_wait[s] = got ? 1u : 0u;
+        if (got) {
+            const uint32_t g = g0 + s, idx = py * S.x_res + px;
+            uint32_t rs = S.rng[idx];
+            float c1 = rng_next(rs), c2 = rng_next(rs), c3 = rng_next(rs), c4 = rng_next(rs), c5 = rng_next(rs);
+            const Ray ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
+            pix[g] = idx;
+            W.ray_o[g] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+            W.ray_d[g] = make_float4(ray.d.x, ray.d.y, ray.d.z, -1.0f);
+            W.light[g] = make_float4(0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, rs));
+            W.reduc[g] = make_float4(1.0f, 1.0f, 1.0f, __builtin_bit_cast(float, 0u));
+            W.aov_n[g] = make_float4(0, 0, 0, 0);
+            W.aov_t[g] = make_float4(0, 0, 0, 0);
+            W.aov_b[g] = make_float4(0, 0, 0, 0);
+            W.left[g] = n_samples;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        const unsigned long long m = __ballot(got);
+        if (m) {
+            if (lane == (int)(__ffsll((long long)m) - 1)) atomicAdd(&s_ctl[C_LIVE], (uint32_t)__popcll(m));
+            const uint32_t pos = st_reserve(&s_ctl[C_RQ_TAIL], got);
+            if (got) s_rq[pos & (ST_RQ_CAP - 1u)] = s + 1u;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_ctl[C_LIVE] == 0) s_ctl[C_DONE] = 1;
+    __syncthreads();
+    // from here on the waves run their own loops: NO workgroup barrier below this line
+
+    unsigned c_rays = 0, c_nodes = 0, c_tris = 0;
+    unsigned c_paths = 0, c_bounce = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;
+    unsigned c_wsteps = 0, c_busy = 0, c_nl = 0, c_tl = 0;
+    uint2* spill = W.spill + (size_t)(blockIdx.x * 16u + wave) * (ER_STACK * 64) + lane;
+
+    if (wave < tracers) {
+        // =========================== tracer: er_wf_trace's loop, fed from the ray ring ===========================
+        uint2* stack = s_stack + (size_t)wave * (WF_LDS_STACK * 64) + lane;
+        Trav T;
+        trav_begin(T, f3s(0), f3(0, 0, 1), false, -1, 0.0f);
+        bool busy = false;
+        uint32_t my_pos = ST_NONE;      // reserved position of the ray ring this lane is waiting at
+        uint32_t ls = 0, kind = 0, rec = 0;   // the ray in hand: local slot, kind, index of its records (g, or g + W.slots)
+        uint32_t idle = 0, progress = 0;
+        while (true) {
+            // idle lanes without a reservation take one; idle lanes poll theirs
+            const bool need = !busy && my_pos == ST_NONE;
+            if (__ballot(need)) {
+                const uint32_t pos = st_reserve(&s_ctl[C_RQ_HEAD], need);
+                if (need) my_pos = pos;
+            }
+            uint32_t v = 0;
+            if (!busy) v = v_rq[my_pos & (ST_RQ_CAP - 1u)];
+            const unsigned long long ready = __ballot(!busy && v != 0);
+            const unsigned long long bm0 = __ballot(busy);
+            // taking rays costs the whole wave a pair of dependent loads: do it for several lanes at once, or when nobody traces
+            if (ready != 0 && ((unsigned)__popcll(ready) >= refill_min || bm0 == 0)) {
+                if (!busy && v != 0) {
+                    s_rq[my_pos & (ST_RQ_CAP - 1u)] = 0;
+                    my_pos = ST_NONE;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (!busy && v != 0) {
+                    const uint32_t e = v - 1u;
+                    ls = e & ((1u << ST_KIND_SHIFT) - 1u);
+                    kind = e >> ST_KIND_SHIFT;
+                    rec = g0 + ls + (kind == 2u ? W.slots : 0u);
+                    const bool shadow = kind != 0u;
+                    const float4 ro = shadow ? W.sh_o[rec] : W.ray_o[rec];
+                    const float4 rd = shadow ? W.sh_d[rec] : W.ray_d[rec];
+                    trav_begin(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), shadow, shadow ? __builtin_bit_cast(int, ro.w) : -1,
+                               shadow ? rd.w : __builtin_inff());
+                    c_rays++;
+                    busy = true;
+                }
+            }
+            const unsigned long long bm = __ballot(busy);
+            if (bm == 0) {
+                if (v_ctl[C_DONE]) break;
+                __builtin_amdgcn_s_sleep(2);
+                const uint32_t pr = v_ctl[C_RQ_TAIL] + v_ctl[C_SQ_TAIL];
+                if (pr != progress) { progress = pr; idle = 0; }
+                if (++idle > ST_WATCHDOG) {
+                    if (lane == 0) { atomicOr(status, 1u); s_ctl[C_DONE] = 1; }
+                    break;
+                }
+                continue;
+            }
+            idle = 0;
+            bool finished = false, do_step = false;
+            TravStep st;
+            st.node = false; st.tri = false; st.two = false; st.tslot = 0; st.noff = 0; st.toff = 0;
+            if (busy) {
+                if (S.node_count != 0) do_step = trav_choose(T, S, stack, spill, st);
+                finished = !do_step;
+            }
+            if (COUNT) {
+                c_wsteps++;
+                c_busy += (unsigned)__popcll(bm);
+                c_nl += (unsigned)__popcll(__ballot(st.node));
+                c_tl += (unsigned)__popcll(__ballot(st.tri));
+            }
+            TravData D;
+            trav_fetch(S, st, D);
+            if (busy) {
+                if (do_step) {
+                    if (trav_apply<COUNT>(T, S, st, D, c_nodes, c_tris)) {
+                        W.occluded[rec] = 1;   // a certain occluder ends the shadow query
+                        finished = true;
+                    }
+                } else if (T.shadow) {
+                    W.occluded[rec] = T.overflow ? 3 : (T.s0 >= 0 ? 2 : 0);
+                }
+                if (finished) {
+                    if (T.shadow) {
+                        W.occ_a[rec] = T.s0;
+                        W.occ_b[rec] = T.s1;
+                    } else {
+                        W.hit[rec] = T.s0 >= 0 ? T.s0 : T.s1;
+                        W.hit2[rec] = T.overflow ? -2 : ((T.s0 >= 0 && T.s1 >= 0) ? T.s1 : -1);
+                    }
+                    busy = false;
+                }
+            }
+            // results out, then the slot's in-flight count; the tracer that takes it to zero hands the slot to the shaders
+            if (__ballot(finished)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                bool last = false;
+                uint32_t old = 0;
+                if (finished) {
+                    old = atomicSub(&s_wait[ls], 1u);
+                    last = (old & 0xFFu) == 1u;
+                }
+                if (__ballot(last)) {
+                    const uint32_t pos = st_reserve(&s_ctl[C_SQ_TAIL], last);
+                    if (last) s_sq[pos & (ST_SQ_CAP - 1u)] = (ls | ((old & ST_FIN) ? ST_SQ_FIN : 0u)) + 1u;
+                }
+            }
+        }
+    } else {
+        // =========================== shader: er_wf_shade's step, fed from the shade ring ===========================
+        int* stack = (int*)(W.spill + (size_t)(blockIdx.x * 16u + wave) * (ER_STACK * 64)) + lane;   // exact re-trace (rare): HBM
+        uint32_t my_pos = ST_NONE;
+        bool have = false;
+        uint32_t e = 0;
+        uint32_t idle = 0, spins = 0, progress = 0;
+        while (true) {
+            const bool need = !have && my_pos == ST_NONE;
+            if (__ballot(need)) {
+                const uint32_t pos = st_reserve(&s_ctl[C_SQ_HEAD], need);
+                if (need) my_pos = pos;
+            }
+            if (!have) {
+                const uint32_t v = v_sq[my_pos & (ST_SQ_CAP - 1u)];
+                if (v != 0) {
+                    s_sq[my_pos & (ST_SQ_CAP - 1u)] = 0;
+                    my_pos = ST_NONE;
+                    e = v - 1u;
+                    have = true;
+                }
+            }
+            const unsigned nh = (unsigned)__popcll(__ballot(have));
+            if (nh == 0) {
+                if (v_ctl[C_DONE]) break;
+                __builtin_amdgcn_s_sleep(2);
+                const uint32_t pr = v_ctl[C_RQ_TAIL] + v_ctl[C_SQ_TAIL];
+                if (pr != progress) { progress = pr; idle = 0; }
+                if (++idle > ST_WATCHDOG) {
+                    if (lane == 0) { atomicOr(status, 2u); s_ctl[C_DONE] = 1; }
+                    break;
+                }
+                continue;
+            }
+            idle = 0;
+            if (nh < batch_min && spins < 64u) {     // a fuller batch costs the same instructions: wait a little for one
+                spins++;
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+            spins = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            bool push_closest = false, push_shadow = false, push_light = false, retire = false;
+            const uint32_t ls = e & 0xFFFFu;
+            const uint32_t slot = g0 + ls;
+            bool want_pixel = false;
+            uint32_t rs = 0;
+            if (have) {
+                const bool fin_only = (e & ST_SQ_FIN) != 0;
+                uint32_t idx = pix[slot];
+                uint32_t px = idx % S.x_res, py = idx / S.x_res;
+                float4 L4 = W.light[slot], R4 = W.reduc[slot];
+                F3 light = f3(L4.x, L4.y, L4.z), reduction = f3(R4.x, R4.y, R4.z);
+                rs = __builtin_bit_cast(uint32_t, L4.w);
+                uint32_t packed = __builtin_bit_cast(uint32_t, R4.w);
+                uint32_t bounce = packed & 0xFFFFu;
+                if (packed & WF_PENDING_BIT) {   // resolve the previous bounce's shadow query
+                    int occ = W.occluded[slot];
+                    if (occ >= 2) {
+                        float4 so = W.sh_o[slot], sd = W.sh_d[slot];
+                        Ray sr;
+                        sr.o = f3(so.x, so.y, so.z);
+                        sr.d = f3(sd.x, sd.y, sd.z);
+                        occ = resolve_shadow<COUNT>(S, stack, sr, __builtin_bit_cast(int, so.w), sd.w, occ, W.occ_a[slot], W.occ_b[slot], c_nodes, c_tris) ? 1 : 0;
+                    }
+                    float4 c = occ ? W.c_occ[slot] : W.c_vis[slot];
+                    light = light + f3(c.x, c.y, c.z);
+                }
+                if (EXT && (packed & WF_LPENDING_BIT)) {   // ... then its point-light query (second half of the shadow records)
+                    const uint32_t q = slot + W.slots;
+                    int occ = W.occluded[q];
+                    if (occ >= 2) {
+                        float4 so = W.sh_o[q], sd = W.sh_d[q];
+                        Ray sr;
+                        sr.o = f3(so.x, so.y, so.z);
+                        sr.d = f3(sd.x, sd.y, sd.z);
+                        occ = resolve_shadow<COUNT>(S, stack, sr, __builtin_bit_cast(int, so.w), sd.w, occ, W.occ_a[q], W.occ_b[q], c_nodes, c_tris) ? 1 : 0;
+                    }
+                    float4 c = occ ? W.c_occ[q] : W.c_vis[q];
+                    light = light + f3(c.x, c.y, c.z);
+                }
+                bool pending = false, lpending = false;
+                bool done = fin_only;
+                Ray ray;
+                ray.o = f3s(0);
+                ray.d = f3(0, 0, 1);
+                float prev_pdf = -1.0f;
+                if (!fin_only) {
+                    float4 o = W.ray_o[slot], d = W.ray_d[slot];
+                    ray.o = f3(o.x, o.y, o.z);
+                    ray.d = f3(d.x, d.y, d.z);
+                    int hslot = resolve_closest<COUNT>(S, stack, ray, W.hit[slot], W.hit2[slot], c_nodes, c_tris);
+                    c_bounce++;
+                    if (EXT) prev_pdf = d.w;
+#define ER_BOUNCE_HDRI_QUERY(sr, self_slot, d_self, cv, co)                                                     \
+    W.sh_o[slot] = make_float4((sr).o.x, (sr).o.y, (sr).o.z, __builtin_bit_cast(float, (int)(self_slot)));      \
+    W.sh_d[slot] = make_float4((sr).d.x, (sr).d.y, (sr).d.z, (d_self));                                          \
+    W.c_vis[slot] = make_float4((cv).x, (cv).y, (cv).z, 0.0f);                                                   \
+    W.c_occ[slot] = make_float4((co).x, (co).y, (co).z, 0.0f)
+#define ER_BOUNCE_LIGHT_QUERY(lr, limit, lv, lo)                                                                \
+    {                                                                                                            \
+        const uint32_t lq = slot + W.slots;                                                                      \
+        const F3 lv_ = (lv), lo_ = (lo);                                                                         \
+        W.sh_o[lq] = make_float4((lr).o.x, (lr).o.y, (lr).o.z, __builtin_bit_cast(float, -1));                   \
+        W.sh_d[lq] = make_float4((lr).d.x, (lr).d.y, (lr).d.z, (limit));                                         \
+        W.c_vis[lq] = make_float4(lv_.x, lv_.y, lv_.z, 0.0f);                                                    \
+        W.c_occ[lq] = make_float4(lo_.x, lo_.y, lo_.z, 0.0f);                                                    \
+    }
+#define ER_BOUNCE_FIRST_HIT(n, t, b)                                                                            \
+    W.aov_n[slot] = make_float4((n).x, (n).y, (n).z, 0.0f);                                                      \
+    W.aov_t[slot] = make_float4((t).x, (t).y, (t).z, 0.0f);                                                      \
+    W.aov_b[slot] = make_float4((b).x, (b).y, (b).z, 0.0f)
+#include "er_bounce.inc"
+#undef ER_BOUNCE_HDRI_QUERY
+#undef ER_BOUNCE_LIGHT_QUERY
+#undef ER_BOUNCE_FIRST_HIT
+                }
+                bool alive = true, fin_next = false;
+                if (done && (pending || lpending)) {
+                    fin_next = true;          // the path is over but a shadow query is in flight: come back once, without a ray
+                } else if (done) {
+                    // src/kernel.cpp:597-645
+                    float4 an = W.aov_n[slot], at = W.aov_t[slot], ab = W.aov_b[slot];
+                    const uint32_t sa = S.samples[idx];
+                    const uint32_t sa2 = accumulate_sample(S, idx, sa, light, f3(an.x, an.y, an.z), f3(at.x, at.y, at.z), f3(ab.x, ab.y, ab.z));
+                    if (sa2 != sa) S.samples[idx] = sa2;
+                    S.rng[idx] = rs;
+                    c_paths++;
+                    const uint32_t left = W.left[slot] - 1;
+                    W.left[slot] = left;
+                    if (left > 0) {
+                        float c1 = rng_next(rs), c2 = rng_next(rs), c3 = rng_next(rs), c4 = rng_next(rs), c5 = rng_next(rs);
+                        ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
+                        light = f3s(0);
+                        reduction = f3s(1);
+                        bounce = 0;
+                        prev_pdf = -1.0f;
+                        W.aov_n[slot] = make_float4(0, 0, 0, 0);
+                        W.aov_t[slot] = make_float4(0, 0, 0, 0);
+                        W.aov_b[slot] = make_float4(0, 0, 0, 0);
+                        push_closest = true;
+                    } else {
+                        alive = false;
+                        want_pixel = true;    // this pixel is finished: the slot takes the next one (below, as a wave)
+                    }
+                } else {
+                    push_closest = true;
+                }
+                push_shadow = pending;
+                push_light = EXT && lpending;
+                if (alive) {
+                    if (!fin_next) {
+                        W.ray_o[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+                        W.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, EXT ? prev_pdf : -1.0f);
+                    }
+                    W.light[slot] = make_float4(light.x, light.y, light.z, __builtin_bit_cast(float, rs));
+                    W.reduc[slot] = make_float4(reduction.x, reduction.y, reduction.z,
+                                                __builtin_bit_cast(float, bounce | (pending ? WF_PENDING_BIT : 0u) | ((EXT && lpending) ? WF_LPENDING_BIT : 0u)));
+                    s_wait[ls] = (push_closest ? 1u : 0u) + (push_shadow ? 1u : 0u) + (push_light ? 1u : 0u) + (fin_next ? ST_FIN : 0u);
+                }
+            }
+            // slots whose pixel is finished take the next pixel (first sample: its own RNG stream from the RNG plane)
+            if (__ballot(want_pixel)) {
+                uint32_t px = 0, py = 0;
+                const bool got = st_take_pixel(S, ticket, want_pixel, px, py);
+                if (got) {
+                    const uint32_t idx = py * S.x_res + px;
+                    uint32_t r2 = S.rng[idx];
+                    float c1 = rng_next(r2), c2 = rng_next(r2), c3 = rng_next(r2), c4 = rng_next(r2), c5 = rng_next(r2);
+                    const Ray ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
+                    pix[slot] = idx;
+                    W.ray_o[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+                    W.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, -1.0f);
+                    W.light[slot] = make_float4(0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, r2));
+                    W.reduc[slot] = make_float4(1.0f, 1.0f, 1.0f, __builtin_bit_cast(float, 0u));
+                    W.aov_n[slot] = make_float4(0, 0, 0, 0);
+                    W.aov_t[slot] = make_float4(0, 0, 0, 0);
+                    W.aov_b[slot] = make_float4(0, 0, 0, 0);
+                    W.left[slot] = n_samples;
+                    s_wait[ls] = 1u;
+                    push_closest = true;
+                } else if (want_pixel) {
+                    retire = true;
+                }
+            }
+            // the slot's records are written: publish its rays
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            {
+                const unsigned long long mc = __ballot(push_closest), ms = __ballot(push_shadow), ml = EXT ? __ballot(push_light) : 0ull;
+                const unsigned nc = (unsigned)__popcll(mc), ns = (unsigned)__popcll(ms), nl = (unsigned)__popcll(ml);
+                if (nc + ns + nl) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&s_ctl[C_RQ_TAIL], nc + ns + nl);
+                    base = __shfl(base, 0, 64);
+                    if (push_closest) s_rq[(base + (uint32_t)__popcll(mc & below)) & (ST_RQ_CAP - 1u)] = ls + 1u;
+                    if (push_shadow) s_rq[(base + nc + (uint32_t)__popcll(ms & below)) & (ST_RQ_CAP - 1u)] = (ls | (1u << ST_KIND_SHIFT)) + 1u;
+                    if (EXT && push_light) s_rq[(base + nc + ns + (uint32_t)__popcll(ml & below)) & (ST_RQ_CAP - 1u)] = (ls | (2u << ST_KIND_SHIFT)) + 1u;
+                }
+                const unsigned long long mr = __ballot(retire);
+                if (mr) {
+                    uint32_t oldl = 0;
+                    const uint32_t nr = (uint32_t)__popcll(mr);
+                    if (lane == 0) {
+                        oldl = atomicSub(&s_ctl[C_LIVE], nr);
+                        if (oldl == nr) s_ctl[C_DONE] = 1;     // the workgroup's last slot has retired
+                    }
+                }
+            }
+            have = false;
+        }
+    }
+    unsigned t0 = st_wave_sum(c_paths), t1 = st_wave_sum(c_bounce), t2 = st_wave_sum(c_rays), t3 = st_wave_sum(c_shaded), t4 = st_wave_sum(c_hdri);
+    unsigned t5 = 0, t6 = 0, t7 = 0;
+    if (COUNT) { t5 = st_wave_sum(c_nodes); t6 = st_wave_sum(c_tris); t7 = st_wave_sum(c_texels); }
+    if (lane == 0) {
+        if (t0) atomicAdd(&S.counters->paths, (unsigned long long)t0);
+        if (t1) atomicAdd(&S.counters->bounce_samples, (unsigned long long)t1);
+        if (t2) atomicAdd(&S.counters->rays, (unsigned long long)t2);
+        if (t3) atomicAdd(&S.counters->shaded_hits, (unsigned long long)t3);
+        if (t4) atomicAdd(&S.counters->hdri_samples, (unsigned long long)t4);
+        if (COUNT) {
+            atomicAdd(&S.counters->node_visits, (unsigned long long)t5);
+            atomicAdd(&S.counters->tri_tests, (unsigned long long)t6);
+            atomicAdd(&S.counters->texel_fetches, (unsigned long long)t7);
+            atomicAdd(&S.counters->trace_wave_steps, (unsigned long long)c_wsteps);
+            atomicAdd(&S.counters->trace_busy_lanes, (unsigned long long)c_busy);
+            atomicAdd(&S.counters->trace_node_lanes, (unsigned long long)c_nl);
+            atomicAdd(&S.counters->trace_tri_lanes, (unsigned long long)c_tl);
+        }
+    }
+}
+
+hipError_t er_probe_stream(const char** which) {
+    hipFuncAttributes a;
+    *which = "er_stream_kernel";
+    return hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false>);
+}
+
+void er_launch_stream(const DevScene& S, const WfState& W, uint32_t* pix, uint32_t* ticket, uint32_t* status, uint32_t n_samples, bool count,
+                      uint32_t blocks, uint32_t tracers, hipStream_t stream) {
+    static const uint32_t refill_min = [] {
+        const char* e = getenv("ER_STREAM_REFILL_MIN");
+        int v = e ? atoi(e) : 4;
+        return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+    }();
+    static const uint32_t batch_min = [] {
+        const char* e = getenv("ER_STREAM_BATCH_MIN");
+        int v = e ? atoi(e) : 48;
+        return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+    }();
+    if (S.owned_tile_count == 0 || n_samples == 0) return;
+    (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
+    const bool ext = er_ext_active(S);
+    auto k = count ? (ext ? er_stream_kernel<true, true> : er_stream_kernel<true, false>) : (ext ? er_stream_kernel<false, true> : er_stream_kernel<false, false>);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(1024), 0, stream, S, W, pix, ticket, status, n_samples, tracers, refill_min, batch_min);
+}

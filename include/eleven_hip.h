@@ -121,6 +121,8 @@ typedef struct ErSceneDesc {
 #define ER_FLAG_MEGAKERNEL   4u   /* v0: one wave per 8x8 tile, wave-synchronous bounce loop over the binary BVH */
 #define ER_FLAG_FUSED        16u  /* persistent waves, lane-asynchronous: trace steps + batched shading, no barrier */
 #define ER_FLAG_WAVEFRONT    32u  /* one trace + one shade launch per bounce over compacted ray queues */
+#define ER_FLAG_STREAM       256u /* one launch per call, one resident workgroup per CU: tracer waves and shader waves feed each
+                                     other through rings in LDS (er_stream.hip) */
 #define ER_FLAG_PROFILE      8u   /* bracket every trace / shade launch with HIP events (see er_get_profile) */
 #define ER_FLAG_GPU_BUILD    64u  /* build the acceleration structure on the GPU (linear BVH: several times faster to
                                      build, slower to trace; falls back to the host SAH build if the tree would be too

@@ -229,12 +229,16 @@ def test_fused_schedule_equals_wavefront_schedule(scene_kind):
     a = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_WAVEFRONT)
     b = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_FUSED)
     c = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_FUSED, chunks=[3, 4])
+    d = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_STREAM)               # ... and so does the CU-resident streaming schedule
+    e = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_STREAM, chunks=[2, 5])
     for p in ("beauty", "normal", "tangent", "bitangent"):
-        assert (a[p].view(np.uint32) == b[p].view(np.uint32)).all(), p
-        assert (a[p].view(np.uint32) == c[p].view(np.uint32)).all(), p
-    assert (a["rng"] == b["rng"]).all() and (a["samples"] == b["samples"]).all()
-    assert a["counters"]["bounce_samples"] == b["counters"]["bounce_samples"]
-    assert a["counters"]["paths"] == b["counters"]["paths"]
+        for other in (b, c, d, e):
+            assert (a[p].view(np.uint32) == other[p].view(np.uint32)).all(), p
+    for other in (b, d):
+        assert (a["rng"] == other["rng"]).all() and (a["samples"] == other["samples"]).all()
+        assert a["counters"]["bounce_samples"] == other["counters"]["bounce_samples"]
+        assert a["counters"]["paths"] == other["counters"]["paths"]
+        assert a["counters"]["rays"] == other["counters"]["rays"]
 
 
 def _empty_scene(x_res, y_res):
@@ -247,7 +251,7 @@ def _empty_scene(x_res, y_res):
     return sc
 
 
-@pytest.mark.parametrize("flags", [abi.FLAG_WAVEFRONT, abi.FLAG_FUSED, abi.FLAG_MEGAKERNEL])
+@pytest.mark.parametrize("flags", [abi.FLAG_WAVEFRONT, abi.FLAG_FUSED, abi.FLAG_MEGAKERNEL, abi.FLAG_STREAM])
 def test_edge_cases_bit_exact(oracle_mod, flags):
     """Inputs at the edges of the domain, in every schedule: no triangles at all (every ray sees the HDRI), a frame
     smaller than one tile and frames with partial tiles on both edges, zero-area and duplicated triangles (exactly
@@ -272,9 +276,11 @@ def _window_schedules_agree(sc, spp, max_bounces, rank, world, mega_ties=0.0, ex
     w = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_WAVEFRONT | extra_flags)
     f = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_FUSED | extra_flags)
     m = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_MEGAKERNEL | extra_flags)
+    st = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_STREAM | extra_flags)
     owned = w["samples"].reshape(w["beauty"].shape[:2]) > 1
     for p in ("beauty", "normal", "tangent", "bitangent"):
         assert (w[p].view(np.uint32) == f[p].view(np.uint32)).all(), p
+        assert (w[p].view(np.uint32) == st[p].view(np.uint32)).all(), p
         differ = (w[p].view(np.uint32) != m[p].view(np.uint32)).any(-1)
         assert differ.sum() <= mega_ties * owned.sum(), (p, int(differ.sum()))
     assert (w["rng"] == f["rng"]).all() and (w["rng"] != m["rng"]).sum() <= mega_ties * owned.sum()
