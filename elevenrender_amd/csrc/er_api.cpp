@@ -297,26 +297,16 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         s->stream_tracers = 10;
         if (const char* e = getenv("ER_STREAM_TRACERS")) s->stream_tracers = (uint32_t)std::min(12, std::max(1, atoi(e)));   // tuning knob
         const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
-        const size_t sh = lights_on ? 2 : 1;
-        if ((rc = upload(s->d_wf4, nullptr, slots * (7 + 4 * sh), s->stream)) != ER_OK) return rc;
-        if ((rc = upload(s->d_wf1, nullptr, slots * (4 + 3 * sh) + 2, s->stream)) != ER_OK) return rc;
+        if ((rc = upload(s->d_wf4, nullptr, slots * er_stream_record_bytes(lights_on) / sizeof(float4), s->stream)) != ER_OK) return rc;
+        if ((rc = upload(s->d_wf1, nullptr, 2, s->stream)) != ER_OK) return rc;        // [1] status word
         if ((rc = upload(s->d_spill, nullptr, (size_t)s->stream_blocks * 16 * ER_BVH_MAX_DEPTH * 64, s->stream)) != ER_OK) return rc;
-        WfState W{};
-        float4* f = s->d_wf4.p;
-        W.ray_o = f; W.ray_d = f + slots; W.light = f + 2 * slots; W.reduc = f + 3 * slots;
-        W.aov_n = f + 4 * slots; W.aov_t = f + 5 * slots; W.aov_b = f + 6 * slots;
-        W.sh_o = f + 7 * slots; W.sh_d = W.sh_o + sh * slots; W.c_vis = W.sh_d + sh * slots; W.c_occ = W.c_vis + sh * slots;
-        uint32_t* u = s->d_wf1.p;
-        W.hit = (int*)u; W.left = u + slots; W.hit2 = (int*)(u + 2 * slots);
-        W.occluded = (int*)(u + 3 * slots); W.occ_a = W.occluded + sh * slots; W.occ_b = W.occ_a + sh * slots;
-        s->stream_pix = u + (3 + 3 * sh) * slots;
-        s->stream_ctl = s->stream_pix + slots;             // [0] pixel ticket, [1] status
+        s->stream_ctl = s->d_wf1.p;
+        s->stream_lights = lights_on;
         HIP_TRY(hipMemsetAsync(s->stream_ctl, 0, 2 * sizeof(uint32_t), s->stream));
-        W.spill = s->d_spill.p;
-        W.slots = (uint32_t)slots;
-        W.pool = 0; W.pools = 1;
+        // the workgroups' pixel rings: (pixel, samples left) entries, one per pixel of the workgroup's share
+        s->stream_ring_cap = (uint32_t)((owned.size() + s->stream_blocks - 1) / s->stream_blocks) * 64u;
+        if ((rc = upload(s->d_ticket, nullptr, (size_t)s->stream_blocks * std::max<uint32_t>(s->stream_ring_cap, 64u) * 2, s->stream)) != ER_OK) return rc;
         s->wf.clear();
-        s->wf.push_back(W);
     } else if (s->params.flags & ER_FLAG_WAVEFRONT) {
         // wavefront path state: one slot per owned pixel lane.
         // SLOT POOLS: the owned tiles are dealt round-robin to `pools` independent path pools, each with its own
@@ -463,7 +453,8 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     if (s->params.flags & ER_FLAG_FUSED) {
         er_launch_fused(s->dev, s->d_ticket.p, s->d_spill.p, n, count, s->fused_blocks, s->stream);
     } else if (s->params.flags & ER_FLAG_STREAM) {
-        er_launch_stream(s->dev, s->wf[0], s->stream_pix, s->stream_ctl, s->stream_ctl + 1, n, count, s->stream_blocks, s->stream_tracers, s->stream);
+        er_launch_stream(s->dev, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
+                         s->stream_blocks, s->stream_tracers, s->stream);
     } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
         er_launch_render(s->dev, n, count, s->stream);
     }

@@ -180,8 +180,8 @@ struct ErScene {
     DevBuf<uint2> d_spill;
     DevBuf<uint32_t> d_guide, d_ticket;
     uint32_t fused_blocks = 0;
-    uint32_t stream_blocks = 0, stream_tracers = 0;     // streaming schedule (er_stream.hip): workgroups; tracer waves of the 16
-    uint32_t* stream_pix = nullptr;                     //   per-slot pixel, inside d_wf1
+    uint32_t stream_blocks = 0, stream_tracers = 0, stream_ring_cap = 0;     // streaming schedule (er_stream.hip): workgroups; tracer waves of the 16
+    bool stream_lights = false;                         //   slot records carry the point-light query's line
     uint32_t* stream_ctl = nullptr;                     //   [0] pixel ticket, [1] status word
     std::vector<WfState> wf;              // slot pools (see er_render_begin)
     std::vector<hipStream_t> pool_streams;   // pool 0 runs on `stream`, pool p > 0 on pool_streams[p - 1]

@@ -10,9 +10,11 @@ struct WfState;
 #define ER_STREAM_SLOTS 2048u     // slots (pixels in flight) per workgroup; one workgroup of 16 waves per CU
 #endif
 
-// W: the wavefront schedule's slot records with blocks * ER_STREAM_SLOTS slots (W.slots; shadow records doubled with the
-// point-light extension), W.spill: 16 * ER_BVH_MAX_DEPTH * 64 entries per workgroup.  pix: one word per slot (its pixel),
-// ticket: one word (zeroed by the launch), status: one word, 0 unless a wave's watchdog fired.
-void er_launch_stream(const DevScene& S, const WfState& W, uint32_t* pix, uint32_t* ticket, uint32_t* status, uint32_t n_samples, bool count,
-                      uint32_t blocks, uint32_t tracers, hipStream_t stream);
+// records: slots * er_stream_record_bytes(lights) bytes (slots = blocks * ER_STREAM_SLOTS; lights: the scene uses the point-light
+// extension, whose queries take a third line per slot); spill: 16 * ER_BVH_MAX_DEPTH * 64 uint2 entries per workgroup; ring:
+// blocks * ring_cap uint2 entries (the workgroups' pixel rings; ring_cap = 64 * ceil(owned tiles / blocks)); status: one
+// word, 0 unless a wave's watchdog fired.
+void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, void* ring, uint32_t ring_cap, uint32_t* status,
+                      uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream);
+uint32_t er_stream_record_bytes(bool lights);
 hipError_t er_probe_stream(const char** which);

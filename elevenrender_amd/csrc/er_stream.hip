@@ -6,10 +6,14 @@
 //
 //   * ONE launch per call; one workgroup of 16 waves per CU, resident for the whole call.  The first `tracers` waves only
 //     trace, the others only shade (the split is a launch argument);
-//   * a workgroup owns ST_SLOTS slots.  A slot holds one pixel at a time: it runs that pixel's samples one after the other
-//     (one RNG stream) and then takes the next pixel from a global ticket; its state lives in HBM exactly as in the
-//     wavefront schedule, but it is only ever touched by waves of its own workgroup -- i.e. of one CU, which share the
-//     vector L1 -- so workgroup-scope release/acquire (a wait for the wave's own stores) is all the ordering needed;
+//   * a workgroup owns a fixed share of the pixels (the owned tiles, dealt round-robin to the workgroups) and ER_STREAM_SLOTS
+//     slots.  A slot runs ONE sample of a pixel, puts the pixel back at the tail of the workgroup's pixel ring (HBM; entry =
+//     pixel, samples left) and takes the pixel at its head: a pixel's samples are one RNG stream and must run one after
+//     the other, but with single samples as the unit all of a workgroup's pixels advance side by side and finish
+//     together (with whole pixels as the unit the call ended in a long tail of last pixels).  Slot state lives in HBM
+//     exactly as in the wavefront schedule, but slots, ring and the planes of the workgroup's pixels are only ever touched
+//     by waves of that workgroup -- i.e. of one CU, which share the vector L1 -- so workgroup-scope release/acquire (a wait
+//     for the wave's own stores) is all the ordering needed;
 //   * the two kinds of waves feed each other through two rings in LDS: rays to trace (closest-hit and shadow queries) and
 //     slots to shade.  A per-slot counter in LDS holds the number of rays of the slot still in flight; the tracer that
 //     finishes the last one appends the slot to the shade ring.  A consumer LANE reserves a ring position (one LDS atomic
@@ -42,7 +46,7 @@ namespace {
 #define ST_SQ_FIN 0x10000u       // the same flag in a shade-ring entry
 #define ST_NONE 0xFFFFFFFFu
 #define ST_MAX_TRACERS 12
-enum { C_RQ_HEAD = 0, C_RQ_TAIL, C_SQ_HEAD, C_SQ_TAIL, C_LIVE, C_DONE, C_WORDS };
+enum { C_RQ_HEAD = 0, C_RQ_TAIL, C_SQ_HEAD, C_SQ_TAIL, C_LIVE, C_DONE, C_PX_HEAD, C_PX_TAIL, C_PX_COUNT, C_INIT, C_WORDS };
 #define ST_WATCHDOG 1500000u     // idle polls (>= 128 cycles each) without any ring activity in the workgroup before a wave gives up
 #define WF_PENDING_BIT 0x10000u  // per-slot flags in reduc.w, as in er_wavefront.hip: bounce (bits 0-15) | pending HDRI shadow query
 #define WF_LPENDING_BIT 0x20000u //   | pending point-light query
@@ -65,37 +69,79 @@ __device__ __forceinline__ uint32_t st_reserve(uint32_t* counter, bool want) {
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
-// the next owned pixel for every lane that wants one (global ticket over the owned tiles, 64 pixels each; pixels of border
-// tiles that fall outside the image are skipped).  All lanes of the wave call.
-__device__ __forceinline__ bool st_take_pixel(const DevScene& S, uint32_t* ticket, bool want, uint32_t& px, uint32_t& py) {
-    const uint32_t total = S.owned_tile_count * 64u;
-    bool got = false;
-    while (true) {
-        const unsigned long long m = __ballot(want && !got);
-        if (m == 0) break;
-        const unsigned lane = threadIdx.x & 63;
-        const unsigned leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(ticket, (uint32_t)__popcll(m));
-        base = __shfl(base, leader, 64);
-        if (base >= total) break;
-        if (want && !got) {
-            const uint32_t k = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (k < total) {
-                const uint32_t tile = S.owned_tiles[k >> 6], l = k & 63u;
-                px = (tile % S.tiles_x) * ER_TILE + (l & 7u);
-                py = (tile / S.tiles_x) * ER_TILE + (l >> 3);
-                got = px < S.x_res && py < S.y_res;
-            }
-        }
+// The slot records of the wavefront schedule (er_wavefront.h: the same fields with the same meaning), laid out slot by slot.
+//   * ONE base pointer: the kernel holds tracer and shader code side by side and both keep many uniform values in scalar
+//     registers; twenty plane pointers are forty of them (a first build reloaded spilled scalars 85 times per iteration of
+//     the tracer loop).  A field's address is base + a 32-bit byte offset (scalar-base addressing form);
+//   * records, not planes: the shade ring delivers slots in the order their rays finish, so a wave's 64 slots are scattered
+//     over the workgroup's slots; with one plane per field every 16-byte access pulled in the records of seven other
+//     slots (L2 hit rate 47 %, 1.5x the fabric reads of the wavefront schedule); a slot's fields now share its own lines.
+//     Line 0 holds everything the tracers read and write, line 1 the rest, line 2 the point-light query.
+#define ST_STRIDE_PLAIN 256u
+#define ST_STRIDE_LIGHTS 384u
+struct StState {
+    char* base;
+    uint2* spill;
+    uint32_t slots, stride;
+    // a shadow record index >= slots addresses the point-light query of slot (index - slots), as in the wavefront schedule
+    template <class T, uint32_t OFF, uint32_t LOFF>
+    __device__ __forceinline__ T& fld2(uint32_t i) const {
+        const bool l = i >= slots;
+        return *(T*)(base + (size_t)((l ? i - slots : i) * stride + (l ? LOFF : OFF)));
     }
-    return got;
+    template <class T, uint32_t OFF>
+    __device__ __forceinline__ T& fld(uint32_t i) const { return *(T*)(base + (size_t)(i * stride + OFF)); }
+    __device__ __forceinline__ float4& ray_o(uint32_t i) const { return fld<float4, 0>(i); }
+    __device__ __forceinline__ float4& ray_d(uint32_t i) const { return fld<float4, 16>(i); }
+    __device__ __forceinline__ float4& sh_o(uint32_t i) const { return fld2<float4, 32, 256>(i); }
+    __device__ __forceinline__ float4& sh_d(uint32_t i) const { return fld2<float4, 48, 272>(i); }
+    __device__ __forceinline__ int& hit(uint32_t i) const { return fld<int, 64>(i); }
+    __device__ __forceinline__ int& hit2(uint32_t i) const { return fld<int, 68>(i); }
+    __device__ __forceinline__ int& occluded(uint32_t i) const { return fld2<int, 72, 288>(i); }
+    __device__ __forceinline__ int& occ_a(uint32_t i) const { return fld2<int, 76, 292>(i); }
+    __device__ __forceinline__ int& occ_b(uint32_t i) const { return fld2<int, 80, 296>(i); }
+    __device__ __forceinline__ uint32_t& left(uint32_t i) const { return fld<uint32_t, 84>(i); }
+    __device__ __forceinline__ uint32_t& pix(uint32_t i) const { return fld<uint32_t, 88>(i); }
+    __device__ __forceinline__ float4& light(uint32_t i) const { return fld<float4, 96>(i); }
+    __device__ __forceinline__ float4& reduc(uint32_t i) const { return fld<float4, 112>(i); }
+    __device__ __forceinline__ float4& aov_n(uint32_t i) const { return fld<float4, 128>(i); }
+    __device__ __forceinline__ float4& aov_t(uint32_t i) const { return fld<float4, 144>(i); }
+    __device__ __forceinline__ float4& aov_b(uint32_t i) const { return fld<float4, 160>(i); }
+    __device__ __forceinline__ float4& c_vis(uint32_t i) const { return fld2<float4, 176, 304>(i); }
+    __device__ __forceinline__ float4& c_occ(uint32_t i) const { return fld2<float4, 192, 320>(i); }
+};
+
+// pixel k of workgroup b's share: tile b + (k / 64) * workgroups of the owned tiles, lane k % 64 (false: outside the image)
+__device__ __forceinline__ bool st_pixel_of(const DevScene& S, uint32_t b, uint32_t nb, uint32_t k, uint32_t& px, uint32_t& py) {
+    const uint32_t t = b + (k >> 6) * nb, l = k & 63u;
+    if (t >= S.owned_tile_count) return false;
+    const uint32_t tile = S.owned_tiles[t];
+    px = (tile % S.tiles_x) * ER_TILE + (l & 7u);
+    py = (tile / S.tiles_x) * ER_TILE + (l >> 3);
+    return px < S.x_res && py < S.y_res;
+}
+
+// first camera ray of a sample of pixel idx in slot g (src/kernel.cpp:492-506); the pixel's RNG state comes from its plane
+__device__ __forceinline__ void st_begin_sample(const DevScene& S, const StState& W, uint32_t g, uint32_t idx, uint32_t left) {
+    const uint32_t px = idx % S.x_res, py = idx / S.x_res;
+    uint32_t rs = S.rng[idx];
+    float c1 = rng_next(rs), c2 = rng_next(rs), c3 = rng_next(rs), c4 = rng_next(rs), c5 = rng_next(rs);
+    const Ray ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
+    W.pix(g) = idx;
+    W.ray_o(g) = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+    W.ray_d(g) = make_float4(ray.d.x, ray.d.y, ray.d.z, -1.0f);
+    W.light(g) = make_float4(0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, rs));
+    W.reduc(g) = make_float4(1.0f, 1.0f, 1.0f, __builtin_bit_cast(float, 0u));
+    W.aov_n(g) = make_float4(0, 0, 0, 0);
+    W.aov_t(g) = make_float4(0, 0, 0, 0);
+    W.aov_b(g) = make_float4(0, 0, 0, 0);
+    W.left(g) = left;
 }
 
 }  // namespace
 
 template <bool COUNT, bool EXT>
-__global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, WfState W, uint32_t* pix, uint32_t* ticket, uint32_t* status,
+__global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, StState W, uint2* ring_base, uint32_t ring_cap, uint32_t* status,
                                                           uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min) {
     __shared__ uint2 s_stack[ST_MAX_TRACERS * WF_LDS_STACK * 64];
     constexpr uint32_t ST_RQ_CAP = ST_RQ_CAP_OF(EXT);
@@ -116,32 +162,40 @@ __global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, WfState W, 
     for (uint32_t i = threadIdx.x; i < ST_SQ_CAP; i += 1024) s_sq[i] = 0;
     if (threadIdx.x < C_WORDS) s_ctl[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t s = threadIdx.x; s < ER_STREAM_SLOTS; s += 1024) {
+    // this workgroup's pixels in the order of its tiles: the first ER_STREAM_SLOTS valid ones start in the slots, the others
+    // wait in the pixel ring (entry = pixel, samples left; .y == 0 marks an empty cell)
+    uint2* ring = ring_base + (size_t)blockIdx.x * ring_cap;
+    for (uint32_t s = threadIdx.x; s < ER_STREAM_SLOTS; s += 1024) s_wait[s] = 0;
+    for (uint32_t k = threadIdx.x; k < ring_cap; k += 1024) ring[k] = make_uint2(0u, 0u);
+    __syncthreads();
+    for (uint32_t k0 = 0; k0 < ring_cap; k0 += 1024) {
+        const uint32_t k = k0 + threadIdx.x;
         uint32_t px = 0, py = 0;
-        const bool got = st_take_pixel(S, ticket, n_samples > 0, px, py);
-        s_wait[s] = got ? 1u : 0u;
-        if (got) {
-            const uint32_t g = g0 + s, idx = py * S.x_res + px;
-            uint32_t rs = S.rng[idx];
-            float c1 = rng_next(rs), c2 = rng_next(rs), c3 = rng_next(rs), c4 = rng_next(rs), c5 = rng_next(rs);
-            const Ray ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
-            pix[g] = idx;
-            W.ray_o[g] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
-            W.ray_d[g] = make_float4(ray.d.x, ray.d.y, ray.d.z, -1.0f);
-            W.light[g] = make_float4(0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, rs));
-            W.reduc[g] = make_float4(1.0f, 1.0f, 1.0f, __builtin_bit_cast(float, 0u));
-            W.aov_n[g] = make_float4(0, 0, 0, 0);
-            W.aov_t[g] = make_float4(0, 0, 0, 0);
-            W.aov_b[g] = make_float4(0, 0, 0, 0);
-            W.left[g] = n_samples;
+        const bool valid = n_samples > 0 && k < ring_cap && st_pixel_of(S, blockIdx.x, gridDim.x, k, px, py);
+        const uint32_t v = st_reserve(&s_ctl[C_INIT], valid);      // (rank among the valid pixels; order does not matter)
+        const bool to_slot = valid && v < ER_STREAM_SLOTS;
+        const uint32_t idx = py * S.x_res + px;
+        if (to_slot) {
+            st_begin_sample(S, W, g0 + v, idx, n_samples);
+            s_wait[v] = 1u;
+        } else if (valid) {
+            ring[v - ER_STREAM_SLOTS] = make_uint2(idx, n_samples);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        const unsigned long long m = __ballot(got);
+        const unsigned long long m = __ballot(to_slot);
         if (m) {
             if (lane == (int)(__ffsll((long long)m) - 1)) atomicAdd(&s_ctl[C_LIVE], (uint32_t)__popcll(m));
-            const uint32_t pos = st_reserve(&s_ctl[C_RQ_TAIL], got);
-            if (got) s_rq[pos & (ST_RQ_CAP - 1u)] = s + 1u;
+            const uint32_t pos = st_reserve(&s_ctl[C_RQ_TAIL], to_slot);
+            if (to_slot) s_rq[pos & (ST_RQ_CAP - 1u)] = v + 1u;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t nv = s_ctl[C_INIT];
+        const uint32_t in_ring = nv > ER_STREAM_SLOTS ? nv - ER_STREAM_SLOTS : 0u;
+        s_ctl[C_PX_HEAD] = 0;
+        s_ctl[C_PX_TAIL] = in_ring;
+        s_ctl[C_PX_COUNT] = in_ring;
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_ctl[C_LIVE] == 0) s_ctl[C_DONE] = 1;
@@ -163,35 +217,36 @@ __global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, WfState W, 
         uint32_t ls = 0, kind = 0, rec = 0;   // the ray in hand: local slot, kind, index of its records (g, or g + W.slots)
         uint32_t idle = 0, progress = 0;
         while (true) {
-            // idle lanes without a reservation take one; idle lanes poll theirs
-            const bool need = !busy && my_pos == ST_NONE;
-            if (__ballot(need)) {
-                const uint32_t pos = st_reserve(&s_ctl[C_RQ_HEAD], need);
-                if (need) my_pos = pos;
-            }
-            uint32_t v = 0;
-            if (!busy) v = v_rq[my_pos & (ST_RQ_CAP - 1u)];
-            const unsigned long long ready = __ballot(!busy && v != 0);
+            // idle lanes reserve a ring position and poll it; all of this is skipped while fewer than refill_min lanes are idle
+            // (it costs the whole wave ~40 instructions and, when rays are taken, a pair of dependent loads)
             const unsigned long long bm0 = __ballot(busy);
-            // taking rays costs the whole wave a pair of dependent loads: do it for several lanes at once, or when nobody traces
-            if (ready != 0 && ((unsigned)__popcll(ready) >= refill_min || bm0 == 0)) {
-                if (!busy && v != 0) {
-                    s_rq[my_pos & (ST_RQ_CAP - 1u)] = 0;
-                    my_pos = ST_NONE;
+            if (64u - (unsigned)__popcll(bm0) >= refill_min || bm0 == 0) {
+                const bool need = !busy && my_pos == ST_NONE;
+                if (__ballot(need)) {
+                    const uint32_t pos = st_reserve(&s_ctl[C_RQ_HEAD], need);
+                    if (need) my_pos = pos;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                if (!busy && v != 0) {
-                    const uint32_t e = v - 1u;
-                    ls = e & ((1u << ST_KIND_SHIFT) - 1u);
-                    kind = e >> ST_KIND_SHIFT;
-                    rec = g0 + ls + (kind == 2u ? W.slots : 0u);
-                    const bool shadow = kind != 0u;
-                    const float4 ro = shadow ? W.sh_o[rec] : W.ray_o[rec];
-                    const float4 rd = shadow ? W.sh_d[rec] : W.ray_d[rec];
-                    trav_begin(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), shadow, shadow ? __builtin_bit_cast(int, ro.w) : -1,
-                               shadow ? rd.w : __builtin_inff());
-                    c_rays++;
-                    busy = true;
+                uint32_t v = 0;
+                if (!busy) v = v_rq[my_pos & (ST_RQ_CAP - 1u)];
+                if (__ballot(v != 0)) {
+                    if (v != 0) {
+                        s_rq[my_pos & (ST_RQ_CAP - 1u)] = 0;
+                        my_pos = ST_NONE;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (v != 0) {
+                        const uint32_t e = v - 1u;
+                        ls = e & ((1u << ST_KIND_SHIFT) - 1u);
+                        kind = e >> ST_KIND_SHIFT;
+                        rec = g0 + ls + (kind == 2u ? W.slots : 0u);
+                        const bool shadow = kind != 0u;
+                        const float4 ro = shadow ? W.sh_o(rec) : W.ray_o(rec);
+                        const float4 rd = shadow ? W.sh_d(rec) : W.ray_d(rec);
+                        trav_begin(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), shadow, shadow ? __builtin_bit_cast(int, ro.w) : -1,
+                                   shadow ? rd.w : __builtin_inff());
+                        c_rays++;
+                        busy = true;
+                    }
                 }
             }
             const unsigned long long bm = __ballot(busy);
@@ -225,19 +280,19 @@ __global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, WfState W, 
             if (busy) {
                 if (do_step) {
                     if (trav_apply<COUNT>(T, S, st, D, c_nodes, c_tris)) {
-                        W.occluded[rec] = 1;   // a certain occluder ends the shadow query
+                        W.occluded(rec) = 1;   // a certain occluder ends the shadow query
                         finished = true;
                     }
                 } else if (T.shadow) {
-                    W.occluded[rec] = T.overflow ? 3 : (T.s0 >= 0 ? 2 : 0);
+                    W.occluded(rec) = T.overflow ? 3 : (T.s0 >= 0 ? 2 : 0);
                 }
                 if (finished) {
                     if (T.shadow) {
-                        W.occ_a[rec] = T.s0;
-                        W.occ_b[rec] = T.s1;
+                        W.occ_a(rec) = T.s0;
+                        W.occ_b(rec) = T.s1;
                     } else {
-                        W.hit[rec] = T.s0 >= 0 ? T.s0 : T.s1;
-                        W.hit2[rec] = T.overflow ? -2 : ((T.s0 >= 0 && T.s1 >= 0) ? T.s1 : -1);
+                        W.hit(rec) = T.s0 >= 0 ? T.s0 : T.s1;
+                        W.hit2(rec) = T.overflow ? -2 : ((T.s0 >= 0 && T.s1 >= 0) ? T.s1 : -1);
                     }
                     busy = false;
                 }
@@ -303,39 +358,38 @@ __global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, WfState W, 
             const uint32_t ls = e & 0xFFFFu;
             const uint32_t slot = g0 + ls;
             bool want_pixel = false;
-            uint32_t rs = 0;
+            uint32_t rs = 0, left_after = 0, done_idx = 0;
             if (have) {
                 const bool fin_only = (e & ST_SQ_FIN) != 0;
-                uint32_t idx = pix[slot];
-                uint32_t px = idx % S.x_res, py = idx / S.x_res;
-                float4 L4 = W.light[slot], R4 = W.reduc[slot];
+                uint32_t idx = W.pix(slot);
+                float4 L4 = W.light(slot), R4 = W.reduc(slot);
                 F3 light = f3(L4.x, L4.y, L4.z), reduction = f3(R4.x, R4.y, R4.z);
                 rs = __builtin_bit_cast(uint32_t, L4.w);
                 uint32_t packed = __builtin_bit_cast(uint32_t, R4.w);
                 uint32_t bounce = packed & 0xFFFFu;
                 if (packed & WF_PENDING_BIT) {   // resolve the previous bounce's shadow query
-                    int occ = W.occluded[slot];
+                    int occ = W.occluded(slot);
                     if (occ >= 2) {
-                        float4 so = W.sh_o[slot], sd = W.sh_d[slot];
+                        float4 so = W.sh_o(slot), sd = W.sh_d(slot);
                         Ray sr;
                         sr.o = f3(so.x, so.y, so.z);
                         sr.d = f3(sd.x, sd.y, sd.z);
-                        occ = resolve_shadow<COUNT>(S, stack, sr, __builtin_bit_cast(int, so.w), sd.w, occ, W.occ_a[slot], W.occ_b[slot], c_nodes, c_tris) ? 1 : 0;
+                        occ = resolve_shadow<COUNT>(S, stack, sr, __builtin_bit_cast(int, so.w), sd.w, occ, W.occ_a(slot), W.occ_b(slot), c_nodes, c_tris) ? 1 : 0;
                     }
-                    float4 c = occ ? W.c_occ[slot] : W.c_vis[slot];
+                    float4 c = occ ? W.c_occ(slot) : W.c_vis(slot);
                     light = light + f3(c.x, c.y, c.z);
                 }
                 if (EXT && (packed & WF_LPENDING_BIT)) {   // ... then its point-light query (second half of the shadow records)
                     const uint32_t q = slot + W.slots;
-                    int occ = W.occluded[q];
+                    int occ = W.occluded(q);
                     if (occ >= 2) {
-                        float4 so = W.sh_o[q], sd = W.sh_d[q];
+                        float4 so = W.sh_o(q), sd = W.sh_d(q);
                         Ray sr;
                         sr.o = f3(so.x, so.y, so.z);
                         sr.d = f3(sd.x, sd.y, sd.z);
-                        occ = resolve_shadow<COUNT>(S, stack, sr, __builtin_bit_cast(int, so.w), sd.w, occ, W.occ_a[q], W.occ_b[q], c_nodes, c_tris) ? 1 : 0;
+                        occ = resolve_shadow<COUNT>(S, stack, sr, __builtin_bit_cast(int, so.w), sd.w, occ, W.occ_a(q), W.occ_b(q), c_nodes, c_tris) ? 1 : 0;
                     }
-                    float4 c = occ ? W.c_occ[q] : W.c_vis[q];
+                    float4 c = occ ? W.c_occ(q) : W.c_vis(q);
                     light = light + f3(c.x, c.y, c.z);
                 }
                 bool pending = false, lpending = false;
@@ -345,30 +399,30 @@ __global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, WfState W, 
                 ray.d = f3(0, 0, 1);
                 float prev_pdf = -1.0f;
                 if (!fin_only) {
-                    float4 o = W.ray_o[slot], d = W.ray_d[slot];
+                    float4 o = W.ray_o(slot), d = W.ray_d(slot);
                     ray.o = f3(o.x, o.y, o.z);
                     ray.d = f3(d.x, d.y, d.z);
-                    int hslot = resolve_closest<COUNT>(S, stack, ray, W.hit[slot], W.hit2[slot], c_nodes, c_tris);
+                    int hslot = resolve_closest<COUNT>(S, stack, ray, W.hit(slot), W.hit2(slot), c_nodes, c_tris);
                     c_bounce++;
                     if (EXT) prev_pdf = d.w;
 #define ER_BOUNCE_HDRI_QUERY(sr, self_slot, d_self, cv, co)                                                     \
-    W.sh_o[slot] = make_float4((sr).o.x, (sr).o.y, (sr).o.z, __builtin_bit_cast(float, (int)(self_slot)));      \
-    W.sh_d[slot] = make_float4((sr).d.x, (sr).d.y, (sr).d.z, (d_self));                                          \
-    W.c_vis[slot] = make_float4((cv).x, (cv).y, (cv).z, 0.0f);                                                   \
-    W.c_occ[slot] = make_float4((co).x, (co).y, (co).z, 0.0f)
+    W.sh_o(slot) = make_float4((sr).o.x, (sr).o.y, (sr).o.z, __builtin_bit_cast(float, (int)(self_slot)));      \
+    W.sh_d(slot) = make_float4((sr).d.x, (sr).d.y, (sr).d.z, (d_self));                                          \
+    W.c_vis(slot) = make_float4((cv).x, (cv).y, (cv).z, 0.0f);                                                   \
+    W.c_occ(slot) = make_float4((co).x, (co).y, (co).z, 0.0f)
 #define ER_BOUNCE_LIGHT_QUERY(lr, limit, lv, lo)                                                                \
     {                                                                                                            \
         const uint32_t lq = slot + W.slots;                                                                      \
         const F3 lv_ = (lv), lo_ = (lo);                                                                         \
-        W.sh_o[lq] = make_float4((lr).o.x, (lr).o.y, (lr).o.z, __builtin_bit_cast(float, -1));                   \
-        W.sh_d[lq] = make_float4((lr).d.x, (lr).d.y, (lr).d.z, (limit));                                         \
-        W.c_vis[lq] = make_float4(lv_.x, lv_.y, lv_.z, 0.0f);                                                    \
-        W.c_occ[lq] = make_float4(lo_.x, lo_.y, lo_.z, 0.0f);                                                    \
+        W.sh_o(lq) = make_float4((lr).o.x, (lr).o.y, (lr).o.z, __builtin_bit_cast(float, -1));                   \
+        W.sh_d(lq) = make_float4((lr).d.x, (lr).d.y, (lr).d.z, (limit));                                         \
+        W.c_vis(lq) = make_float4(lv_.x, lv_.y, lv_.z, 0.0f);                                                    \
+        W.c_occ(lq) = make_float4(lo_.x, lo_.y, lo_.z, 0.0f);                                                    \
     }
 #define ER_BOUNCE_FIRST_HIT(n, t, b)                                                                            \
-    W.aov_n[slot] = make_float4((n).x, (n).y, (n).z, 0.0f);                                                      \
-    W.aov_t[slot] = make_float4((t).x, (t).y, (t).z, 0.0f);                                                      \
-    W.aov_b[slot] = make_float4((b).x, (b).y, (b).z, 0.0f)
+    W.aov_n(slot) = make_float4((n).x, (n).y, (n).z, 0.0f);                                                      \
+    W.aov_t(slot) = make_float4((t).x, (t).y, (t).z, 0.0f);                                                      \
+    W.aov_b(slot) = make_float4((b).x, (b).y, (b).z, 0.0f)
 #include "er_bounce.inc"
 #undef ER_BOUNCE_HDRI_QUERY
 #undef ER_BOUNCE_LIGHT_QUERY
@@ -379,29 +433,17 @@ __global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, WfState W, 
                     fin_next = true;          // the path is over but a shadow query is in flight: come back once, without a ray
                 } else if (done) {
                     // src/kernel.cpp:597-645
-                    float4 an = W.aov_n[slot], at = W.aov_t[slot], ab = W.aov_b[slot];
+                    float4 an = W.aov_n(slot), at = W.aov_t(slot), ab = W.aov_b(slot);
                     const uint32_t sa = S.samples[idx];
                     const uint32_t sa2 = accumulate_sample(S, idx, sa, light, f3(an.x, an.y, an.z), f3(at.x, at.y, at.z), f3(ab.x, ab.y, ab.z));
                     if (sa2 != sa) S.samples[idx] = sa2;
                     S.rng[idx] = rs;
                     c_paths++;
-                    const uint32_t left = W.left[slot] - 1;
-                    W.left[slot] = left;
-                    if (left > 0) {
-                        float c1 = rng_next(rs), c2 = rng_next(rs), c3 = rng_next(rs), c4 = rng_next(rs), c5 = rng_next(rs);
-                        ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
-                        light = f3s(0);
-                        reduction = f3s(1);
-                        bounce = 0;
-                        prev_pdf = -1.0f;
-                        W.aov_n[slot] = make_float4(0, 0, 0, 0);
-                        W.aov_t[slot] = make_float4(0, 0, 0, 0);
-                        W.aov_b[slot] = make_float4(0, 0, 0, 0);
-                        push_closest = true;
-                    } else {
-                        alive = false;
-                        want_pixel = true;    // this pixel is finished: the slot takes the next one (below, as a wave)
-                    }
+                    // the sample is done: the pixel goes back to the ring (below, as a wave) and the slot takes the next one
+                    left_after = W.left(slot) - 1;
+                    done_idx = idx;
+                    alive = false;
+                    want_pixel = true;
                 } else {
                     push_closest = true;
                 }
@@ -409,37 +451,58 @@ __global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, WfState W, 
                 push_light = EXT && lpending;
                 if (alive) {
                     if (!fin_next) {
-                        W.ray_o[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
-                        W.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, EXT ? prev_pdf : -1.0f);
+                        W.ray_o(slot) = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
+                        W.ray_d(slot) = make_float4(ray.d.x, ray.d.y, ray.d.z, EXT ? prev_pdf : -1.0f);
                     }
-                    W.light[slot] = make_float4(light.x, light.y, light.z, __builtin_bit_cast(float, rs));
-                    W.reduc[slot] = make_float4(reduction.x, reduction.y, reduction.z,
+                    W.light(slot) = make_float4(light.x, light.y, light.z, __builtin_bit_cast(float, rs));
+                    W.reduc(slot) = make_float4(reduction.x, reduction.y, reduction.z,
                                                 __builtin_bit_cast(float, bounce | (pending ? WF_PENDING_BIT : 0u) | ((EXT && lpending) ? WF_LPENDING_BIT : 0u)));
                     s_wait[ls] = (push_closest ? 1u : 0u) + (push_shadow ? 1u : 0u) + (push_light ? 1u : 0u) + (fin_next ? ST_FIN : 0u);
                 }
             }
-            // slots whose pixel is finished take the next pixel (first sample: its own RNG stream from the RNG plane)
+            // finished samples: pixel back to the tail of the pixel ring (unless that was its last sample), next pixel from the head
             if (__ballot(want_pixel)) {
-                uint32_t px = 0, py = 0;
-                const bool got = st_take_pixel(S, ticket, want_pixel, px, py);
-                if (got) {
-                    const uint32_t idx = py * S.x_res + px;
-                    uint32_t r2 = S.rng[idx];
-                    float c1 = rng_next(r2), c2 = rng_next(r2), c3 = rng_next(r2), c4 = rng_next(r2), c5 = rng_next(r2);
-                    const Ray ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
-                    pix[slot] = idx;
-                    W.ray_o[slot] = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
-                    W.ray_d[slot] = make_float4(ray.d.x, ray.d.y, ray.d.z, -1.0f);
-                    W.light[slot] = make_float4(0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, r2));
-                    W.reduc[slot] = make_float4(1.0f, 1.0f, 1.0f, __builtin_bit_cast(float, 0u));
-                    W.aov_n[slot] = make_float4(0, 0, 0, 0);
-                    W.aov_t[slot] = make_float4(0, 0, 0, 0);
-                    W.aov_b[slot] = make_float4(0, 0, 0, 0);
-                    W.left[slot] = n_samples;
-                    s_wait[ls] = 1u;
-                    push_closest = true;
+                const bool back = want_pixel && left_after > 0;
+                const unsigned long long mb = __ballot(back);
+                if (mb) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the pixel's planes and RNG state first, then its entry
+                    const uint32_t pos = st_reserve(&s_ctl[C_PX_TAIL], back);
+                    if (back) ring[pos % ring_cap] = make_uint2(done_idx, left_after);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    if (lane == 0) atomicAdd(&s_ctl[C_PX_COUNT], (uint32_t)__popcll(mb));     // counted only once written
+                }
+                // take up to `want` entries: the count may go negative for a moment when several waves ask at once
+                const unsigned long long mw = __ballot(want_pixel);
+                const int nw = __popcll(mw);
+                int granted = 0;
+                uint32_t hb = 0;
+                if (lane == 0) {
+                    const int old = (int)atomicSub(&s_ctl[C_PX_COUNT], (uint32_t)nw);
+                    granted = old < 0 ? 0 : (old < nw ? old : nw);
+                    if (granted < nw) atomicAdd(&s_ctl[C_PX_COUNT], (uint32_t)(nw - granted));
+                    if (granted) hb = atomicAdd(&s_ctl[C_PX_HEAD], (uint32_t)granted);
+                }
+                granted = __shfl(granted, 0, 64);
+                hb = __shfl(hb, 0, 64);
+                const int rank = __popcll(mw & below);
+                if (want_pixel && rank < granted) {
+                    uint2* cell = ring + (hb + (uint32_t)rank) % ring_cap;
+                    // the cell's writer may still be on its way (positions are handed out before they are written)
+                    uint32_t y = 0, guard = 0;
+                    while ((y = __hip_atomic_load(&cell->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0 && ++guard < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const uint32_t nidx = cell->x;
+                    *cell = make_uint2(0u, 0u);
+                    if (y != 0) {
+                        st_begin_sample(S, W, slot, nidx, y);
+                        s_wait[ls] = 1u;
+                        push_closest = true;
+                    } else {
+                        atomicOr(status, 4u);    // (cannot happen: a granted entry was never written)
+                        retire = true;
+                    }
                 } else if (want_pixel) {
-                    retire = true;
+                    retire = true;      // nothing left in the ring: the pixels still unfinished are all in flight in other slots
                 }
             }
             // the slot's records are written: publish its rays
@@ -495,11 +558,11 @@ hipError_t er_probe_stream(const char** which) {
     return hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false>);
 }
 
-void er_launch_stream(const DevScene& S, const WfState& W, uint32_t* pix, uint32_t* ticket, uint32_t* status, uint32_t n_samples, bool count,
-                      uint32_t blocks, uint32_t tracers, hipStream_t stream) {
+void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, void* ring, uint32_t ring_cap, uint32_t* status,
+                      uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream) {
     static const uint32_t refill_min = [] {
         const char* e = getenv("ER_STREAM_REFILL_MIN");
-        int v = e ? atoi(e) : 4;
+        int v = e ? atoi(e) : 8;
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     static const uint32_t batch_min = [] {
@@ -508,8 +571,14 @@ void er_launch_stream(const DevScene& S, const WfState& W, uint32_t* pix, uint32
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     if (S.owned_tile_count == 0 || n_samples == 0) return;
-    (void)hipMemsetAsync(ticket, 0, sizeof(uint32_t), stream);
     const bool ext = er_ext_active(S);
     auto k = count ? (ext ? er_stream_kernel<true, true> : er_stream_kernel<true, false>) : (ext ? er_stream_kernel<false, true> : er_stream_kernel<false, false>);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(1024), 0, stream, S, W, pix, ticket, status, n_samples, tracers, refill_min, batch_min);
+    StState st;
+    st.base = (char*)records;
+    st.spill = (uint2*)spill;
+    st.slots = slots;
+    st.stride = er_stream_record_bytes(lights);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(1024), 0, stream, S, st, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min);
 }
+
+uint32_t er_stream_record_bytes(bool lights) { return lights ? ST_STRIDE_LIGHTS : ST_STRIDE_PLAIN; }

@@ -24,7 +24,7 @@ def main():
     w = csv.writer(out)
     w.writerow(["pass", "kernel", "counter", "dispatches", "sum", "mean_per_dispatch"])
     for r in rows:
-        if r[1].startswith("er_wf_trace") or r[1].startswith("er_wf_shade"):
+        if r[1].startswith("er_wf_trace") or r[1].startswith("er_wf_shade") or r[1].startswith("er_stream") or r[1].startswith("er_fused"):
             w.writerow([r[0], r[1], r[2], r[3], f"{r[4]:.6g}", f"{r[5]:.6g}"])
 
 main()

@@ -1,0 +1,18 @@
+#!/bin/bash
+# PMC passes for the streaming schedule's single kernel (kernel trace only).  GPU box, repo root: bash tools/pmc_stream.sh r02
+set -o pipefail
+tag=${1:-r02}
+out=gpurun_out/pmc_stream_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+pass() {
+  name=$1; shift
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/$name -o run -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-trace-phase --schedule stream > $out/$name.log 2>&1 || echo "pass $name failed"
+  echo "pass $name done"
+}
+pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAVES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE
+pass tcp_stall TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum GRBM_GUI_ACTIVE
+pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE
+pass hbm FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE
+ls $out
