@@ -301,8 +301,8 @@ def main():
         t_launches = max(1, prof["trace_launches"])
         trace_ms_avg = prof["trace_ms"] / t_launches
         sched = {abi.FLAG_WAVEFRONT: "wavefront", abi.FLAG_FUSED: "fused", abi.FLAG_MEGAKERNEL: "megakernel", abi.FLAG_STREAM: "stream"}.get(prof["schedule"], "?")
-        kernel_name = {"wavefront": "er_wf_trace", "fused": "er_fused_kernel", "megakernel": "er_render_kernel"}.get(sched, "?")
-        if sched != "wavefront":
+        kernel_name = {"wavefront": "er_wf_trace", "fused": "er_fused_kernel", "megakernel": "er_render_kernel", "stream": "er_stream_kernel"}.get(sched, "?")
+        if sched not in ("wavefront", "stream"):
             layout_b = path_b + (layout_b - trace_b)
             trace_b = path_b      # the single kernel of these schedules does the whole path
         wall_s = max(kernel_ms * 1e-3, 1e-9)        # device time of the whole timed region (HIP events on the library's stream)
@@ -345,9 +345,14 @@ def main():
 
         traffic = None
         tf = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes
-        if os.path.exists(tf) and world == 1 and args.config == "C2" and args.tris == 1_000_000:
+        if os.path.exists(tf) and world == 1 and args.config == "C2" and args.tris == 1_000_000 and not (args.width or args.height):
             try:
-                traffic = json.load(open(tf)).get("er_wf_trace_hbm_bytes_per_launch")
+                tj = json.load(open(tf))
+                if sched == "wavefront":
+                    traffic = tj.get("er_wf_trace_hbm_bytes_per_launch")
+                elif sched == "stream" and tj.get("er_stream_kernel_hbm_bytes_per_step"):
+                    # one launch of the streaming kernel runs all K steps of the call; the PMC passes measured bytes per step
+                    traffic = tj["er_stream_kernel_hbm_bytes_per_step"] * args.steps / launches
             except Exception:
                 traffic = None
         value = samples / elapsed / 1e6
@@ -364,7 +369,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": kernel_name,
-                         "definition": "achieved = all traversal bytes of the timed region (64 B/node visit + 36 B/triangle test, SURVEY 8d) / device time of the region",
+                         "definition": "achieved = all traversal bytes of the timed region (64 B/node visit + 36 B/triangle test, SURVEY 8d) / device time of the region"
+                                       + ("; the streaming schedule is ONE kernel (traversal and shading waves side by side): region time = its launch duration, nothing overlaps it" if sched == "stream" else ""),
                          "peak_measured": round(peak_measured, 1) if peak_measured else None,
                          "peak_measured_copy": round(copy_gbs, 1) if copy_gbs else None, "peak_measured_read": round(read_gbs, 1) if read_gbs else None,
                          "frac_of_measured": round(achieved / peak_measured, 4) if peak_measured else None,

@@ -276,7 +276,16 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     {
         const uint32_t forced = p->flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM);
         uint32_t sched = forced;
-        if (forced == 0) sched = (owned.size() * 64 > 1200000u) ? ER_FLAG_WAVEFRONT : ER_FLAG_FUSED;
+        // measured on MI355X (profiles/r02_schedules_by_size.log): the streaming schedule wins from ~0.2 M owned pixels up on scenes
+        // whose traversal data fit the Infinity Cache (1 M-triangle soup: 640x360 to 3840x2160, also 1/2 .. 1/8 shares of a
+        // 1080p frame); the wavefront schedule keeps the 4K frame of the 9.68 M-triangle scene (C4); the fused kernel the
+        // small frames, which are launch-bound
+        if (forced == 0) {
+            const size_t px = owned.size() * 64;
+            if (px < 150000u) sched = ER_FLAG_FUSED;
+            else if (px > 4000000u && s->tri_count > 4000000u) sched = ER_FLAG_WAVEFRONT;
+            else sched = ER_FLAG_STREAM;
+        }
         else if (forced & (forced - 1)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: more than one schedule flag");
         s->params.flags = (s->params.flags & ~(uint32_t)(ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM)) | sched;
     }
@@ -530,6 +539,15 @@ static int er_wait_impl(ErScene* s, float* elapsed_ms) {
         HIP_TRY(hipStreamSynchronize(s->stream));
     }
     if (elapsed_ms) *elapsed_ms = ms;
+    if ((s->params.flags & ER_FLAG_STREAM) && s->stream_ctl) {
+        // the streaming kernel's waves give up instead of spinning forever if their workgroup makes no progress (er_stream.hip)
+        uint32_t st[2] = {0, 0};
+        HIP_TRY(hipMemcpy(st, s->stream_ctl, sizeof(st), hipMemcpyDeviceToHost));
+        if (st[1] != 0) {
+            HIP_TRY(hipMemset(s->stream_ctl, 0, sizeof(st)));
+            return fail(ER_ERR_STATE, "er_wait: the streaming schedule stopped without finishing (watchdog status " + std::to_string(st[1]) + "); the planes are incomplete");
+        }
+    }
     s->profile = ErProfile{};
     s->profile.schedule = s->params.flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM);
     s->profile.concurrency = (s->params.flags & ER_FLAG_WAVEFRONT) ? (uint32_t)std::max<size_t>(1, s->wf.size()) : 1u;

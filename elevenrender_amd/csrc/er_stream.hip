@@ -47,7 +47,13 @@ namespace {
 #define ST_NONE 0xFFFFFFFFu
 #define ST_MAX_TRACERS 12
 enum { C_RQ_HEAD = 0, C_RQ_TAIL, C_SQ_HEAD, C_SQ_TAIL, C_LIVE, C_DONE, C_PX_HEAD, C_PX_TAIL, C_PX_COUNT, C_INIT, C_WORDS };
-#define ST_WATCHDOG 1500000u     // idle polls (>= 128 cycles each) without any ring activity in the workgroup before a wave gives up
+#ifndef ST_IDLE_SLEEP
+#define ST_IDLE_SLEEP 16         // s_sleep argument (x 64 cycles) of a wave that found nothing to do: every poll of an idle wave is ~25
+#endif                           // instructions taken from the waves that work (a first build spent a fifth of all issue slots polling)
+#ifndef ST_BATCH_SLEEP
+#define ST_BATCH_SLEEP 8         // ... of a shader wave waiting for a fuller batch
+#endif
+#define ST_WATCHDOG 300000u      // idle polls (>= 1000 cycles each) without any ring activity in the workgroup before a wave gives up
 #define WF_PENDING_BIT 0x10000u  // per-slot flags in reduc.w, as in er_wavefront.hip: bounce (bits 0-15) | pending HDRI shadow query
 #define WF_LPENDING_BIT 0x20000u //   | pending point-light query
 
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, StState W, 
             const unsigned long long bm = __ballot(busy);
             if (bm == 0) {
                 if (v_ctl[C_DONE]) break;
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
                 const uint32_t pr = v_ctl[C_RQ_TAIL] + v_ctl[C_SQ_TAIL];
                 if (pr != progress) { progress = pr; idle = 0; }
                 if (++idle > ST_WATCHDOG) {
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, StState W, 
             const unsigned nh = (unsigned)__popcll(__ballot(have));
             if (nh == 0) {
                 if (v_ctl[C_DONE]) break;
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
                 const uint32_t pr = v_ctl[C_RQ_TAIL] + v_ctl[C_SQ_TAIL];
                 if (pr != progress) { progress = pr; idle = 0; }
                 if (++idle > ST_WATCHDOG) {
@@ -347,9 +353,9 @@ __global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, StState W, 
                 continue;
             }
             idle = 0;
-            if (nh < batch_min && spins < 64u) {     // a fuller batch costs the same instructions: wait a little for one
+            if (nh < batch_min && spins < 24u) {     // a fuller batch costs the same instructions: wait a little for one
                 spins++;
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(ST_BATCH_SLEEP);
                 continue;
             }
             spins = 0;

@@ -115,9 +115,9 @@ typedef struct ErSceneDesc {
 #define ER_FLAG_MIS          128u /* extension, default off = reference behaviour (NEE and BRDF-sampled environment both
                                      counted in full, src/kernel.cpp:571-577): balance-heuristic weights per direction */
 #define ER_FLAG_COUNTERS     2u   /* count node visits / triangle tests (slower kernel variant) */
-/* Schedule selection (every schedule computes bit-identical results).  Default: automatic -- the wavefront schedule
- * when this rank owns many pixels (> 1.2M), the lane-asynchronous fused schedule otherwise (few pixels per GPU make
- * the per-bounce launches of the wavefront latency-bound).  The flags force one. */
+/* Schedule selection (every schedule computes bit-identical results).  Default: automatic, by what was measured on
+ * MI355X -- the fused schedule when this rank owns fewer than 150 k pixels (launch-bound frames), the wavefront schedule
+ * for more than 4 M pixels of a scene of more than 4 M triangles, the streaming schedule otherwise.  The flags force one. */
 #define ER_FLAG_MEGAKERNEL   4u   /* v0: one wave per 8x8 tile, wave-synchronous bounce loop over the binary BVH */
 #define ER_FLAG_FUSED        16u  /* persistent waves, lane-asynchronous: trace steps + batched shading, no barrier */
 #define ER_FLAG_WAVEFRONT    32u  /* one trace + one shade launch per bounce over compacted ray queues */

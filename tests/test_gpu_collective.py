@@ -17,7 +17,7 @@ from test_gpu_parity import gpu_render
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("sched", [0, abi.FLAG_WAVEFRONT])
+@pytest.mark.parametrize("sched", [0, abi.FLAG_WAVEFRONT, abi.FLAG_STREAM])
 def test_gather_pass_over_the_loopback_transport_reassembles_the_frame(sched):
     lib = abi.load()
     sc = scenes.soup(5000, 100, 76, seed=9, hdri_size=(64, 32))     # 100x76: partial tiles on both edges

@@ -204,6 +204,15 @@ def test_full_size_properties():
     assert (a["samples"] == 4).mean() > 0.999          # NaN-gated samples are the only exceptions
     assert np.isfinite(a["beauty"]).all() and a["beauty"][..., :3].min() >= 0 and a["beauty"][..., :3].max() <= 10
     assert a["info"] == 4
+    # the whole frame, bit for bit, in the two schedules that matter at this size (the default here is the streaming schedule)
+    full_w = gpu_render(sc, 3, max_bounces=8, flags=abi.FLAG_WAVEFRONT)
+    full_s = gpu_render(sc, 3, max_bounces=8, flags=abi.FLAG_STREAM)
+    for p in ("beauty", "normal", "tangent", "bitangent"):
+        assert (a[p].view(np.uint32) == full_w[p].view(np.uint32)).all(), p
+        assert (a[p].view(np.uint32) == full_s[p].view(np.uint32)).all(), p
+    assert (a["rng"] == full_w["rng"]).all() and (a["rng"] == full_s["rng"]).all()
+    for k in ("paths", "bounce_samples", "rays", "shaded_hits", "hdri_samples"):
+        assert a["counters"][k] == full_w["counters"][k] == full_s["counters"][k], k
     w = gpu_render(sc, 3, max_bounces=8, rank=7, world=64, flags=abi.FLAG_WAVEFRONT)
     m = gpu_render(sc, 3, max_bounces=8, rank=7, world=64, flags=abi.FLAG_MEGAKERNEL)
     f = gpu_render(sc, 3, max_bounces=8, rank=7, world=64, flags=abi.FLAG_FUSED)
@@ -357,7 +366,7 @@ def test_closest_hit_function_level(oracle_mod):
         orc.close()
 
 
-@pytest.mark.parametrize("flags", [abi.FLAG_WAVEFRONT, abi.FLAG_FUSED])
+@pytest.mark.parametrize("flags", [abi.FLAG_WAVEFRONT, abi.FLAG_FUSED, abi.FLAG_STREAM])
 def test_read_back_during_asynchronous_rendering_is_a_sample_boundary_snapshot(flags):
     """The reference reads passes on a second queue while the render thread enqueues samples, unsynchronised
     (src/Managers.cpp:287-302: torn reads).  Here er_read_pass is ordered after everything enqueued so far -- including

@@ -71,7 +71,17 @@ if os.path.exists(l2_path):
             w.writerow([k, d["TCC_HIT_sum"][0], int(h), int(m), round(h / (h + m), 4) if h + m else 0.0])
 
 key = [k for k in traffic if k.startswith("er_wf_trace<false>")]
+# the streaming schedule is one kernel per call: tools/record_run.sh's PMC passes make one call of 1 step (warm-up) and one of 4
+# steps with the uninstrumented variant, so bytes per step = the variant's total / 5
+PMC_STEPS = 5
+skey = [k for k in traffic if k.startswith("er_stream_kernel<false")]
+stream_per_step = None
+if skey:
+    fs = fetch.get(skey[0], {}).get("FETCH_SIZE", [0, 0.0])[1]
+    ws = write.get(skey[0], {}).get("WRITE_SIZE", [0, 0.0])[1]
+    stream_per_step = round((2.0 * fs + ws) * 1024.0 / PMC_STEPS)
 out = {"er_wf_trace_hbm_bytes_per_launch": traffic[key[0]] if key else None,
+       "er_stream_kernel_hbm_bytes_per_step": stream_per_step,
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; bytes = 2*FETCH_SIZE(KB)*1024 + WRITE_SIZE(KB)*1024 "
                "(MI355X_MICROARCH.md HBM section); per launch of one slot pool (a third of the frame's rays)",
        "all_kernels": traffic}
