@@ -344,7 +344,8 @@ def main():
         peak_measured = max(copy_gbs or 0.0, read_gbs or 0.0) or None
 
         traffic = None
-        tf = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")   # HBM bytes per launch from rocprofv3 PMC passes
+        # HBM bytes from rocprofv3 PMC passes (tools/record_run.sh; the wavefront schedule's set was recorded with --schedule wavefront)
+        tf = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}{'wf' if sched == 'wavefront' else ''}_pmc_traffic.json")
         if os.path.exists(tf) and world == 1 and args.config == "C2" and args.tris == 1_000_000 and not (args.width or args.height):
             try:
                 tj = json.load(open(tf))

@@ -144,5 +144,6 @@ def test_closed_welded_mesh_image_parity_and_tie_rate(oracle_mod):
     o = oracle_render(oracle_mod, sc, 4, max_bounces=8, threads=16)
     frac = compare(g, o, min_exact=0.998, what="closed welded mesh, 131072 triangles")
     print(f"tie rate (pixels not bit-exact after 4 spp x 8 bounces): {1 - frac:.2e}")
-    f = gpu_render(sc, 4, max_bounces=8, flags=abi.FLAG_FUSED)
-    assert (f["beauty"].view(np.uint32) == g["beauty"].view(np.uint32)).all()
+    for sched in (abi.FLAG_FUSED, abi.FLAG_WAVEFRONT, abi.FLAG_STREAM):
+        f = gpu_render(sc, 4, max_bounces=8, flags=sched)
+        assert (f["beauty"].view(np.uint32) == g["beauty"].view(np.uint32)).all(), sched
