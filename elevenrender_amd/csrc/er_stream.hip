@@ -44,6 +44,9 @@ namespace {
 #define ST_KIND_SHIFT 13         // ray-ring entry = local slot | kind << 12: 0 closest hit, 1 HDRI shadow query, 2 point-light query
 #define ST_FIN 0x100u            // s_wait flag: when its rays are done the slot is only finalised (ER_WF_FINALIZE_ONLY)
 #define ST_SQ_FIN 0x10000u       // the same flag in a shade-ring entry
+#ifndef ST_THREADS
+#define ST_THREADS 1024          // 16 waves per CU: four per SIMD, 128 VGPRs each
+#endif
 #define ST_NONE 0xFFFFFFFFu
 #define ST_MAX_TRACERS 12
 enum { C_RQ_HEAD = 0, C_RQ_TAIL, C_SQ_HEAD, C_SQ_TAIL, C_LIVE, C_DONE, C_PX_HEAD, C_PX_TAIL, C_PX_COUNT, C_INIT, C_WORDS };
@@ -147,7 +150,7 @@ __device__ __forceinline__ void st_begin_sample(const DevScene& S, const StState
 }  // namespace
 
 template <bool COUNT, bool EXT>
-__global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, StState W, uint2* ring_base, uint32_t ring_cap, uint32_t* status,
+__global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StState W, uint2* ring_base, uint32_t ring_cap, uint32_t* status,
                                                           uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min) {
     __shared__ uint2 s_stack[ST_MAX_TRACERS * WF_LDS_STACK * 64];
     constexpr uint32_t ST_RQ_CAP = ST_RQ_CAP_OF(EXT);
@@ -164,17 +167,17 @@ __global__ __launch_bounds__(1024) void er_stream_kernel(DevScene S, StState W, 
     const unsigned long long below = (1ull << lane) - 1ull;
 
     // ---- start: empty rings, then every slot takes a pixel and queues its first camera ray ----
-    for (uint32_t i = threadIdx.x; i < ST_RQ_CAP; i += 1024) s_rq[i] = 0;
-    for (uint32_t i = threadIdx.x; i < ST_SQ_CAP; i += 1024) s_sq[i] = 0;
+    for (uint32_t i = threadIdx.x; i < ST_RQ_CAP; i += ST_THREADS) s_rq[i] = 0;
+    for (uint32_t i = threadIdx.x; i < ST_SQ_CAP; i += ST_THREADS) s_sq[i] = 0;
     if (threadIdx.x < C_WORDS) s_ctl[threadIdx.x] = 0;
     __syncthreads();
     // this workgroup's pixels in the order of its tiles: the first ER_STREAM_SLOTS valid ones start in the slots, the others
     // wait in the pixel ring (entry = pixel, samples left; .y == 0 marks an empty cell)
     uint2* ring = ring_base + (size_t)blockIdx.x * ring_cap;
-    for (uint32_t s = threadIdx.x; s < ER_STREAM_SLOTS; s += 1024) s_wait[s] = 0;
-    for (uint32_t k = threadIdx.x; k < ring_cap; k += 1024) ring[k] = make_uint2(0u, 0u);
+    for (uint32_t s = threadIdx.x; s < ER_STREAM_SLOTS; s += ST_THREADS) s_wait[s] = 0;
+    for (uint32_t k = threadIdx.x; k < ring_cap; k += ST_THREADS) ring[k] = make_uint2(0u, 0u);
     __syncthreads();
-    for (uint32_t k0 = 0; k0 < ring_cap; k0 += 1024) {
+    for (uint32_t k0 = 0; k0 < ring_cap; k0 += ST_THREADS) {
         const uint32_t k = k0 + threadIdx.x;
         uint32_t px = 0, py = 0;
         const bool valid = n_samples > 0 && k < ring_cap && st_pixel_of(S, blockIdx.x, gridDim.x, k, px, py);
@@ -584,7 +587,7 @@ void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lig
     st.spill = (uint2*)spill;
     st.slots = slots;
     st.stride = er_stream_record_bytes(lights);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(1024), 0, stream, S, st, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(ST_THREADS), 0, stream, S, st, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min);
 }
 
 uint32_t er_stream_record_bytes(bool lights) { return lights ? ST_STRIDE_LIGHTS : ST_STRIDE_PLAIN; }
