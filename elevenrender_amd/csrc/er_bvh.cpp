@@ -32,7 +32,10 @@ struct Box {
     }
 };
 
-const int NBINS = 16;
+#ifndef ER_SAH_BINS
+#define ER_SAH_BINS 16
+#endif
+const int NBINS = ER_SAH_BINS;
 
 struct Builder {
     std::vector<Prim> prims;
