@@ -313,7 +313,9 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         s->stream_lights = lights_on;
         HIP_TRY(hipMemsetAsync(s->stream_ctl, 0, 2 * sizeof(uint32_t), s->stream));
         // the workgroups' pixel rings: (pixel, samples left) entries, one per pixel of the workgroup's share
-        s->stream_ring_cap = (uint32_t)((owned.size() + s->stream_blocks - 1) / s->stream_blocks) * 64u;
+        // (capacity rounded up to a power of two: positions are monotonic 32-bit counters and may wrap)
+        s->stream_ring_cap = 64u;
+        while (s->stream_ring_cap < (uint32_t)((owned.size() + s->stream_blocks - 1) / s->stream_blocks) * 64u) s->stream_ring_cap <<= 1;
         if ((rc = upload(s->d_ticket, nullptr, (size_t)s->stream_blocks * std::max<uint32_t>(s->stream_ring_cap, 64u) * 2, s->stream)) != ER_OK) return rc;
         s->wf.clear();
     } else if (s->params.flags & ER_FLAG_WAVEFRONT) {

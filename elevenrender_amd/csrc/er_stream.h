@@ -12,7 +12,7 @@ struct WfState;
 
 // records: slots * er_stream_record_bytes(lights) bytes (slots = blocks * ER_STREAM_SLOTS; lights: the scene uses the point-light
 // extension, whose queries take a third line per slot); spill: 16 * ER_BVH_MAX_DEPTH * 64 uint2 entries per workgroup; ring:
-// blocks * ring_cap uint2 entries (the workgroups' pixel rings; ring_cap = 64 * ceil(owned tiles / blocks)); status: one
+// blocks * ring_cap uint2 entries (the workgroups' pixel rings; ring_cap = a power of two >= 64 * ceil(owned tiles / blocks)); status: one
 // word, 0 unless a wave's watchdog fired.
 void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, void* ring, uint32_t ring_cap, uint32_t* status,
                       uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream);

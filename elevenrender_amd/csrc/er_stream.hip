@@ -476,7 +476,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 if (mb) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the pixel's planes and RNG state first, then its entry
                     const uint32_t pos = st_reserve(&s_ctl[C_PX_TAIL], back);
-                    if (back) ring[pos % ring_cap] = make_uint2(done_idx, left_after);
+                    if (back) ring[pos & (ring_cap - 1u)] = make_uint2(done_idx, left_after);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane == 0) atomicAdd(&s_ctl[C_PX_COUNT], (uint32_t)__popcll(mb));     // counted only once written
                 }
@@ -495,7 +495,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 hb = __shfl(hb, 0, 64);
                 const int rank = __popcll(mw & below);
                 if (want_pixel && rank < granted) {
-                    uint2* cell = ring + (hb + (uint32_t)rank) % ring_cap;
+                    uint2* cell = ring + ((hb + (uint32_t)rank) & (ring_cap - 1u));
                     // the cell's writer may still be on its way (positions are handed out before they are written)
                     uint32_t y = 0, guard = 0;
                     while ((y = __hip_atomic_load(&cell->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0 && ++guard < (1u << 22)) __builtin_amdgcn_s_sleep(1);
