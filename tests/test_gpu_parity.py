@@ -250,6 +250,22 @@ def test_fused_schedule_equals_wavefront_schedule(scene_kind):
         assert a["counters"]["rays"] == other["counters"]["rays"]
 
 
+def test_streaming_schedule_many_turns_of_the_pixel_ring():
+    """er_stream.hip: a workgroup holds 2048 of its pixels in slots and the others in a ring that every finished sample goes
+    through.  1024x768 = 3072 pixels per workgroup: the ring turns over once per sample, 24 times here (its positions wrap
+    its capacity several times), in one call and in uneven chunks -- bit for bit the wavefront schedule's frame."""
+    sc = scenes.soup(50_000, 1024, 768, seed=21, hdri_size=(256, 128))
+    w = gpu_render(sc, 24, max_bounces=6, flags=abi.FLAG_WAVEFRONT)
+    s1 = gpu_render(sc, 24, max_bounces=6, flags=abi.FLAG_STREAM)
+    s2 = gpu_render(sc, 24, max_bounces=6, flags=abi.FLAG_STREAM, chunks=[1, 7, 16])
+    for other in (s1, s2):
+        for p in ("beauty", "normal", "tangent", "bitangent"):
+            assert (w[p].view(np.uint32) == other[p].view(np.uint32)).all(), p
+        assert (w["rng"] == other["rng"]).all() and (w["samples"] == other["samples"]).all()
+    for k in ("paths", "bounce_samples", "rays", "shaded_hits", "hdri_samples"):
+        assert w["counters"][k] == s1["counters"][k] == s2["counters"][k], k
+
+
 def _empty_scene(x_res, y_res):
     sc = scenes.soup(1, x_res, y_res, seed=3, hdri_size=(64, 32))
     keep = np.zeros(0, np.int64)
