@@ -11,7 +11,8 @@
 //     pixel, samples left) and takes the pixel at its head: a pixel's samples are one RNG stream and must run one after
 //     the other, but with single samples as the unit all of a workgroup's pixels advance side by side and finish
 //     together (with whole pixels as the unit the call ended in a long tail of last pixels).  Slot state lives in HBM
-//     exactly as in the wavefront schedule, but slots, ring and the planes of the workgroup's pixels are only ever touched
+//     with the wavefront schedule's fields (one record per slot, StState below); slots, ring and the planes of the
+//     workgroup's pixels are only ever touched
 //     by waves of that workgroup -- i.e. of one CU, which share the vector L1 -- so workgroup-scope release/acquire (a wait
 //     for the wave's own stores) is all the ordering needed;
 //   * the two kinds of waves feed each other through two rings in LDS: rays to trace (closest-hit and shadow queries) and
@@ -41,7 +42,7 @@ namespace {
 #define ST_POW2_GE(x) ((x) <= 1024u ? 1024u : (x) <= 2048u ? 2048u : (x) <= 4096u ? 4096u : (x) <= 8192u ? 8192u : 16384u)
 #define ST_RQ_CAP_OF(ext) ST_POW2_GE(((ext) ? 3u : 2u) * ER_STREAM_SLOTS + 768u)
 #define ST_SQ_CAP ST_POW2_GE(ER_STREAM_SLOTS + 1024u)
-#define ST_KIND_SHIFT 13         // ray-ring entry = local slot | kind << 12: 0 closest hit, 1 HDRI shadow query, 2 point-light query
+#define ST_KIND_SHIFT 13         // ray-ring entry = local slot | kind << 13: 0 closest hit, 1 HDRI shadow query, 2 point-light query
 #define ST_FIN 0x100u            // s_wait flag: when its rays are done the slot is only finalised (ER_WF_FINALIZE_ONLY)
 #define ST_SQ_FIN 0x10000u       // the same flag in a shade-ring entry
 #ifndef ST_THREADS
@@ -51,8 +52,8 @@ namespace {
 #define ST_MAX_TRACERS 12
 enum { C_RQ_HEAD = 0, C_RQ_TAIL, C_SQ_HEAD, C_SQ_TAIL, C_LIVE, C_DONE, C_PX_HEAD, C_PX_TAIL, C_PX_COUNT, C_INIT, C_WORDS };
 #ifndef ST_IDLE_SLEEP
-#define ST_IDLE_SLEEP 16         // s_sleep argument (x 64 cycles) of a wave that found nothing to do: every poll of an idle wave is ~25
-#endif                           // instructions taken from the waves that work (a first build spent a fifth of all issue slots polling)
+#define ST_IDLE_SLEEP 16         // s_sleep argument (x 64 cycles) of a wave that found nothing to do (4 .. 48 measured: no difference)
+#endif
 #ifndef ST_BATCH_SLEEP
 #define ST_BATCH_SLEEP 8         // ... of a shader wave waiting for a fuller batch
 #endif
