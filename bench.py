@@ -371,8 +371,9 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          # the same counter bytes as a rate over the timed region: what the L2s asked of the fabric (Infinity-Cache hits
                          # are counted, MI355X_MICROARCH.md), against the spec peak and the peak measured in this job
-                         "traffic_GBps": round(traffic * launches / wall_s / 1e9, 1) if traffic else None,
-                         "traffic_frac": round(traffic * launches / wall_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                         # (wavefront: `traffic` is per trace launch of one pool -- the shade launches' bytes are not in it)
+                         "traffic_GBps": round(traffic * (t_launches if sched == "wavefront" else launches) / wall_s / 1e9, 1) if traffic else None,
+                         "traffic_frac": round(traffic * (t_launches if sched == "wavefront" else launches) / wall_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
                          "kernel": kernel_name,
                          "definition": "achieved = all traversal bytes of the timed region (64 B/node visit + 36 B/triangle test, SURVEY 8d) / device time of the region"
                                        + ("; the streaming schedule is ONE kernel (traversal and shading waves side by side): region time = its launch duration, nothing overlaps it" if sched == "stream" else ""),
