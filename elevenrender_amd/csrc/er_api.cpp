@@ -395,6 +395,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     D.tri_attr = s->d_attr.p;
     D.tri_count = s->tri_count;
     D.node_count = bvh2_nodes;
+    D.node8_count = wide_nodes;
     D.prune_margin = lift_bound + 1e-5f * scene_scale;
     D.max_lift = lift_bound;
     D.scene_scale = scene_scale;

@@ -34,6 +34,7 @@ struct DevScene {
     const float4* tri_isect;    // 3 x float4 per slot
     const float4* tri_attr;     // 7 x float4 per slot
     uint32_t tri_count, node_count;
+    uint32_t node8_count;       // wide nodes in nodes8
     uint32_t tri_base_pieces;   // tri_isect == nodes8 + tri_base_pieces (16-byte pieces): one buffer, 32-bit offsets
     float prune_margin;         // lift bound + rounding slack, see trace()
     float max_lift, scene_scale; // inputs of the interval bookkeeping in er_wf_trace

@@ -7,7 +7,9 @@ struct DevScene;
 struct WfState;
 
 #ifndef ER_STREAM_SLOTS
-#define ER_STREAM_SLOTS 2048u     // slots (pixels in flight) per workgroup; one workgroup of 16 waves per CU
+#define ER_STREAM_SLOTS 1024u     // slots (pixels in flight) per workgroup; one workgroup of 16 waves per CU.  Measured on C2 with the
+                                  // top of the tree in LDS: 768 -> 1060, 1024 -> 1330, 1536 -> 1311, 2048 -> 1286 Msamples/s (the LDS the
+                                  // rings of more slots take is worth more as tree levels)
 #endif
 
 // records: slots * er_stream_record_bytes(lights) bytes (slots = blocks * ER_STREAM_SLOTS; lights: the scene uses the point-light

@@ -48,6 +48,15 @@ namespace {
 #ifndef ST_THREADS
 #define ST_THREADS 1024          // 16 waves per CU: four per SIMD, 128 VGPRs each
 #endif
+// north_star: "top BVH levels staged in LDS".  Every workgroup keeps the first ER_STREAM_TOP_NODES wide nodes in LDS (the
+// tree is stored breadth-first: 585 = levels 0-3, 47 KB) and the tracer lanes whose node is one of them read it with
+// ds_read_b128 instead of five global loads: 9 of a ray's 21 node visits on C2.  Measured on C2 (1024 slots): 0 nodes 1240,
+// 73 -> 1274, 256 -> 1286, 585 -> 1330, 800 -> 1331 Msamples/s (profiles/r02_ab_top_levels_in_lds.log).  The reads are
+// issued AFTER the step's global loads have arrived, straight into the registers those would have filled: a first version
+// that fetched them early into registers of their own spilled the tracer loop and ran 2.6x slower.
+#ifndef ER_STREAM_TOP_NODES
+#define ER_STREAM_TOP_NODES 585
+#endif
 #define ST_NONE 0xFFFFFFFFu
 #define ST_MAX_TRACERS 12
 enum { C_RQ_HEAD = 0, C_RQ_TAIL, C_SQ_HEAD, C_SQ_TAIL, C_LIVE, C_DONE, C_PX_HEAD, C_PX_TAIL, C_PX_COUNT, C_INIT, C_WORDS };
@@ -159,6 +168,11 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
     __shared__ uint32_t s_sq[ST_SQ_CAP];
     __shared__ uint32_t s_wait[ER_STREAM_SLOTS];
     __shared__ uint32_t s_ctl[C_WORDS];
+#if ER_STREAM_TOP_NODES > 0
+    __shared__ float4 s_top[ER_STREAM_TOP_NODES * ER_NODE8_PIECES];
+    for (uint32_t i = threadIdx.x; i < ER_STREAM_TOP_NODES * ER_NODE8_PIECES; i += ST_THREADS)
+        s_top[i] = i < S.node8_count * ER_NODE8_PIECES ? S.nodes8[i] : make_float4(0, 0, 0, 0);
+#endif
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t g0 = blockIdx.x * ER_STREAM_SLOTS;          // this workgroup's first slot
@@ -286,7 +300,17 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 c_tl += (unsigned)__popcll(__ballot(st.tri));
             }
             TravData D;
+#if ER_STREAM_TOP_NODES > 0
+            {
+                const bool top = st.node && st.noff < (uint32_t)(ER_STREAM_TOP_NODES * ER_NODE8_PIECES);
+                TravStep sg = st;
+                if (top) sg.node = false;          // (these lanes' node loads go to the shared dummy address)
+                trav_fetch(S, sg, D);
+                if (top) { const float4* q = s_top + st.noff; D.n0 = q[0]; D.n1 = q[1]; D.n2 = q[2]; D.n3 = q[3]; D.n4 = q[4]; }
+            }
+#else
             trav_fetch(S, st, D);
+#endif
             if (busy) {
                 if (do_step) {
                     if (trav_apply<COUNT>(T, S, st, D, c_nodes, c_tris)) {
