@@ -17,9 +17,9 @@
 //     for the wave's own stores) is all the ordering needed;
 //   * the two kinds of waves feed each other through two rings in LDS: rays to trace (closest-hit and shadow queries) and
 //     slots to shade.  A per-slot counter in LDS holds the number of rays of the slot still in flight; the tracer that
-//     finishes the last one appends the slot to the shade ring.  A consumer LANE reserves a ring position (one LDS atomic
-//     per wave and iteration) and polls that cell until a producer has filled it, so a ring never has to be "non-empty"
-//     for a reservation to succeed and no lane waits for another lane's ray;
+//     finishes the last one appends the slot to the shade ring.  Producers write their cells and then add to the ring's
+//     count of written entries; a consumer wave takes min(wanted, count) entries with one LDS atomic (st_take), so a ring
+//     position is only ever held for an entry that exists, and no lane waits for another lane's ray;
 //   * there is no launch boundary between bounces and therefore no tail in which a few long rays hold a launch open: a
 //     tracer lane that finishes a ray takes the next one from the ring, whatever bounce or sample it belongs to.
 //
@@ -37,8 +37,8 @@ using namespace erd;
 
 namespace {
 
-// ring capacities (powers of two).  ray ring: >= 3 rays per slot (2 without the point-light extension) + one reservation per
-// tracer lane; shade ring: >= one entry per slot + one reservation per shader lane
+// ring capacities (powers of two, with room to spare).  ray ring: >= 3 rays per slot (2 without the point-light extension);
+// shade ring: >= one entry per slot
 #define ST_POW2_GE(x) ((x) <= 1024u ? 1024u : (x) <= 2048u ? 2048u : (x) <= 4096u ? 4096u : (x) <= 8192u ? 8192u : 16384u)
 #define ST_RQ_CAP_OF(ext) ST_POW2_GE(((ext) ? 3u : 2u) * ER_STREAM_SLOTS + 768u)
 #define ST_SQ_CAP ST_POW2_GE(ER_STREAM_SLOTS + 1024u)
@@ -59,7 +59,7 @@ namespace {
 #endif
 #define ST_NONE 0xFFFFFFFFu
 #define ST_MAX_TRACERS 12
-enum { C_RQ_HEAD = 0, C_RQ_TAIL, C_SQ_HEAD, C_SQ_TAIL, C_LIVE, C_DONE, C_PX_HEAD, C_PX_TAIL, C_PX_COUNT, C_INIT, C_WORDS };
+enum { C_RQ_HEAD = 0, C_RQ_TAIL, C_RQ_COUNT, C_SQ_HEAD, C_SQ_TAIL, C_SQ_COUNT, C_LIVE, C_DONE, C_PX_HEAD, C_PX_TAIL, C_PX_COUNT, C_INIT, C_WORDS };
 #ifndef ST_IDLE_SLEEP
 #define ST_IDLE_SLEEP 16         // s_sleep argument (x 64 cycles) of a wave that found nothing to do (4 .. 48 measured: no difference)
 #endif
@@ -129,6 +129,25 @@ struct StState {
     __device__ __forceinline__ float4& c_vis(uint32_t i) const { return fld2<float4, 176, 304>(i); }
     __device__ __forceinline__ float4& c_occ(uint32_t i) const { return fld2<float4, 192, 320>(i); }
 };
+
+// Taking entries from a ring (all lanes of the wave call; wave-uniform result).  `count` = entries that have been WRITTEN
+// and not yet handed out; the wave takes min(want, count) of them: `granted`, at positions base .. base + granted - 1.  The
+// count may go negative for a moment when several waves ask at once; it is restored at once.  A position is thus only ever
+// held for an entry that exists (a first version let idle lanes reserve positions AHEAD of the producers and poll them: a lane
+// whose wave then did not poll for a few hundred microseconds had its cell overwritten after the ring wrapped, the ray was
+// lost and the workgroup never finished -- the watchdog's first catch).
+__device__ __forceinline__ int st_take(uint32_t* count, uint32_t* head, int want, uint32_t& base) {
+    int granted = 0;
+    uint32_t hb = 0;
+    if ((threadIdx.x & 63) == 0 && want > 0) {
+        const int old = (int)atomicSub(count, (uint32_t)want);
+        granted = old < 0 ? 0 : (old < want ? old : want);
+        if (granted < want) atomicAdd(count, (uint32_t)(want - granted));
+        if (granted) hb = atomicAdd(head, (uint32_t)granted);
+    }
+    base = __shfl(hb, 0, 64);
+    return __shfl(granted, 0, 64);
+}
 
 // pixel k of workgroup b's share: tile b + (k / 64) * workgroups of the owned tiles, lane k % 64 (false: outside the image)
 __device__ __forceinline__ bool st_pixel_of(const DevScene& S, uint32_t b, uint32_t nb, uint32_t k, uint32_t& px, uint32_t& py) {
@@ -211,6 +230,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
             if (lane == (int)(__ffsll((long long)m) - 1)) atomicAdd(&s_ctl[C_LIVE], (uint32_t)__popcll(m));
             const uint32_t pos = st_reserve(&s_ctl[C_RQ_TAIL], to_slot);
             if (to_slot) s_rq[pos & (ST_RQ_CAP - 1u)] = v + 1u;
+            if (lane == 0) atomicAdd(&s_ctl[C_RQ_COUNT], (uint32_t)__popcll(m));
         }
     }
     __syncthreads();
@@ -237,28 +257,26 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
         Trav T;
         trav_begin(T, f3s(0), f3(0, 0, 1), false, -1, 0.0f);
         bool busy = false;
-        uint32_t my_pos = ST_NONE;      // reserved position of the ray ring this lane is waiting at
         uint32_t ls = 0, kind = 0, rec = 0;   // the ray in hand: local slot, kind, index of its records (g, or g + W.slots)
         uint32_t idle = 0, progress = 0;
         while (true) {
-            // idle lanes reserve a ring position and poll it; all of this is skipped while fewer than refill_min lanes are idle
-            // (it costs the whole wave ~40 instructions and, when rays are taken, a pair of dependent loads)
+            // idle lanes take rays from the ring; skipped while fewer than refill_min lanes are idle (it costs the whole wave ~40
+            // instructions and, when rays are taken, a pair of dependent loads) or the ring has nothing written
             const unsigned long long bm0 = __ballot(busy);
-            if (64u - (unsigned)__popcll(bm0) >= refill_min || bm0 == 0) {
-                const bool need = !busy && my_pos == ST_NONE;
-                if (__ballot(need)) {
-                    const uint32_t pos = st_reserve(&s_ctl[C_RQ_HEAD], need);
-                    if (need) my_pos = pos;
-                }
-                uint32_t v = 0;
-                if (!busy) v = v_rq[my_pos & (ST_RQ_CAP - 1u)];
-                if (__ballot(v != 0)) {
-                    if (v != 0) {
-                        s_rq[my_pos & (ST_RQ_CAP - 1u)] = 0;
-                        my_pos = ST_NONE;
+            if ((64u - (unsigned)__popcll(bm0) >= refill_min || bm0 == 0) && (int)v_ctl[C_RQ_COUNT] > 0) {
+                uint32_t hb = 0;
+                const int granted = st_take(&s_ctl[C_RQ_COUNT], &s_ctl[C_RQ_HEAD], 64 - __popcll(bm0), hb);
+                const bool take = !busy && __popcll(~bm0 & below) < granted;
+                if (granted > 0) {
+                    uint32_t v = 0;
+                    if (take) {
+                        volatile uint32_t* cell = v_rq + ((hb + (uint32_t)__popcll(~bm0 & below)) & (ST_RQ_CAP - 1u));
+                        uint32_t guard = 0;
+                        while ((v = *cell) == 0 && ++guard < (1u << 22)) __builtin_amdgcn_s_sleep(1);   // (its writer is on its way)
+                        *cell = 0;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    if (v != 0) {
+                    if (take && v != 0) {
                         const uint32_t e = v - 1u;
                         ls = e & ((1u << ST_KIND_SHIFT) - 1u);
                         kind = e >> ST_KIND_SHIFT;
@@ -270,6 +288,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                                    shadow ? rd.w : __builtin_inff());
                         c_rays++;
                         busy = true;
+                    } else if (take) {
+                        atomicOr(status, 16u);      // (cannot happen: a granted entry was never written)
                     }
                 }
             }
@@ -341,35 +361,22 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                     last = (old & 0xFFu) == 1u;
                 }
                 if (__ballot(last)) {
+                    const unsigned long long ml = __ballot(last);
                     const uint32_t pos = st_reserve(&s_ctl[C_SQ_TAIL], last);
                     if (last) s_sq[pos & (ST_SQ_CAP - 1u)] = (ls | ((old & ST_FIN) ? ST_SQ_FIN : 0u)) + 1u;
+                    if (lane == 0) atomicAdd(&s_ctl[C_SQ_COUNT], (uint32_t)__popcll(ml));      // (after the cells: LDS is in order per wave)
                 }
             }
         }
     } else {
         // =========================== shader: er_wf_shade's step, fed from the shade ring ===========================
         int* stack = (int*)(W.spill + (size_t)(blockIdx.x * 16u + wave) * (ER_STACK * 64)) + lane;   // exact re-trace (rare): HBM
-        uint32_t my_pos = ST_NONE;
         bool have = false;
         uint32_t e = 0;
         uint32_t idle = 0, spins = 0, progress = 0;
         while (true) {
-            const bool need = !have && my_pos == ST_NONE;
-            if (__ballot(need)) {
-                const uint32_t pos = st_reserve(&s_ctl[C_SQ_HEAD], need);
-                if (need) my_pos = pos;
-            }
-            if (!have) {
-                const uint32_t v = v_sq[my_pos & (ST_SQ_CAP - 1u)];
-                if (v != 0) {
-                    s_sq[my_pos & (ST_SQ_CAP - 1u)] = 0;
-                    my_pos = ST_NONE;
-                    e = v - 1u;
-                    have = true;
-                }
-            }
-            const unsigned nh = (unsigned)__popcll(__ballot(have));
-            if (nh == 0) {
+            const int avail = (int)v_ctl[C_SQ_COUNT];
+            if (avail <= 0) {
                 if (v_ctl[C_DONE]) break;
                 __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
                 const uint32_t pr = v_ctl[C_RQ_TAIL] + v_ctl[C_SQ_TAIL];
@@ -381,12 +388,24 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 continue;
             }
             idle = 0;
-            if (nh < batch_min && spins < 24u) {     // a fuller batch costs the same instructions: wait a little for one
+            if (avail < (int)batch_min && spins < 24u) {     // a fuller batch costs the same instructions: wait a little for one
                 spins++;
                 __builtin_amdgcn_s_sleep(ST_BATCH_SLEEP);
                 continue;
             }
             spins = 0;
+            uint32_t hb = 0;
+            const int granted = st_take(&s_ctl[C_SQ_COUNT], &s_ctl[C_SQ_HEAD], 64, hb);
+            if (granted == 0) continue;          // another wave was quicker
+            have = lane < granted;
+            if (have) {
+                volatile uint32_t* cell = v_sq + ((hb + (uint32_t)lane) & (ST_SQ_CAP - 1u));
+                uint32_t v = 0, guard = 0;
+                while ((v = *cell) == 0 && ++guard < (1u << 22)) __builtin_amdgcn_s_sleep(1);   // (its writer is on its way)
+                *cell = 0;
+                e = v - 1u;
+                if (v == 0) { have = false; atomicOr(status, 8u); }
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             bool push_closest = false, push_shadow = false, push_light = false, retire = false;
             const uint32_t ls = e & 0xFFFFu;
@@ -551,6 +570,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                     if (push_closest) s_rq[(base + (uint32_t)__popcll(mc & below)) & (ST_RQ_CAP - 1u)] = ls + 1u;
                     if (push_shadow) s_rq[(base + nc + (uint32_t)__popcll(ms & below)) & (ST_RQ_CAP - 1u)] = (ls | (1u << ST_KIND_SHIFT)) + 1u;
                     if (EXT && push_light) s_rq[(base + nc + ns + (uint32_t)__popcll(ml & below)) & (ST_RQ_CAP - 1u)] = (ls | (2u << ST_KIND_SHIFT)) + 1u;
+                    if (lane == 0) atomicAdd(&s_ctl[C_RQ_COUNT], nc + ns + nl);      // (after the cells: LDS is in order per wave)
                 }
                 const unsigned long long mr = __ballot(retire);
                 if (mr) {
