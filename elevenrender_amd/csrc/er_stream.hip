@@ -616,7 +616,7 @@ void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lig
                       uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream) {
     static const uint32_t refill_min = [] {
         const char* e = getenv("ER_STREAM_REFILL_MIN");
-        int v = e ? atoi(e) : 8;
+        int v = e ? atoi(e) : 12;
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     static const uint32_t batch_min = [] {

@@ -250,6 +250,23 @@ def test_fused_schedule_equals_wavefront_schedule(scene_kind):
         assert a["counters"]["rays"] == other["counters"]["rays"]
 
 
+def test_streaming_schedule_long_calls_complete():
+    """Regression: with ring positions reserved AHEAD of their producers a cell could be overwritten after the ring had wrapped
+    (a lane whose wave did not poll for a few hundred microseconds), the ray was lost, its workgroup never finished and the
+    watchdog ended the call -- first seen as `er_wait: ... watchdog status 1` on the C2 frame with a 4-sample call followed by
+    a 64-sample one.  The same calls must complete, and count every path."""
+    sc = scenes.soup(1_000_000, 1920, 1080, seed=12345)
+    rm = render.RenderingManager(render.RenderParameters(max_bounces=8, flags=abi.FLAG_STREAM))
+    rm.start_rendering(sc)
+    rm.render(4)
+    rm.render(64)          # raises if the library reports the watchdog
+    c = rm.counters()
+    samples = rm.read_samples()
+    rm.close()
+    assert c["paths"] == 1920 * 1080 * 68
+    assert (samples == 69).mean() > 0.999
+
+
 def test_streaming_schedule_many_turns_of_the_pixel_ring():
     """er_stream.hip: a workgroup holds 2048 of its pixels in slots and the others in a ring that every finished sample goes
     through.  1024x768 = 3072 pixels per workgroup: the ring turns over once per sample, 24 times here (its positions wrap
