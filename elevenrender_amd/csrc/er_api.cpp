@@ -446,6 +446,8 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_render_samples: NULL scene");
     std::lock_guard<std::mutex> lk(s->mtx);
     if (!s->begun) return fail(ER_ERR_STATE, "er_render_samples: er_render_begin has not succeeded");
+    if ((s->params.flags & ER_FLAG_STREAM) && n >= (1u << 24))      // (its pixel-ring entries keep the samples left in 24 bits)
+        return fail(ER_ERR_INVALID_ARG, "er_render_samples: at most 16777215 samples per call in the streaming schedule");
     HIP_TRY(hipSetDevice(s->device));
     if (!s->timing_open) {
         HIP_TRY(hipEventRecord(s->ev_start, s->stream));

@@ -131,23 +131,40 @@ struct StState {
 };
 
 // Taking entries from a ring (all lanes of the wave call; wave-uniform result).  `count` = entries that have been WRITTEN
-// and not yet handed out; the wave takes min(want, count) of them: `granted`, at positions base .. base + granted - 1.  The
-// count may go negative for a moment when several waves ask at once; it is restored at once.  A position is thus only ever
-// held for an entry that exists (a first version let idle lanes reserve positions AHEAD of the producers and poll them: a lane
-// whose wave then did not poll for a few hundred microseconds had its cell overwritten after the ring wrapped, the ray was
-// lost and the workgroup never finished -- the watchdog's first catch).
+// and not yet handed out; the wave takes min(want, count) of them -- `granted`, at positions base .. base + granted - 1 -- with
+// a compare-and-swap, so the count is exact at every instant.  Two earlier protocols, both caught by tests:
+//   * idle lanes reserved positions AHEAD of the producers and polled them: a lane whose wave then did not poll for a few
+//     hundred microseconds had its cell overwritten after the ring wrapped, the ray was lost and the workgroup never
+//     finished (the watchdog's first catch);
+//   * subtract-then-restore (count may dip below zero while several waves ask at once): harmless for the LDS rings, but in
+//     the pixel ring a slot that had just put its pixel back could be refused during another wave's dip, retire, and -- if
+//     every other slot retired too -- leave the pixel in the ring: one pixel of a small frame one sample short, once in
+//     ~50 runs.
 __device__ __forceinline__ int st_take(uint32_t* count, uint32_t* head, int want, uint32_t& base) {
     int granted = 0;
     uint32_t hb = 0;
     if ((threadIdx.x & 63) == 0 && want > 0) {
-        const int old = (int)atomicSub(count, (uint32_t)want);
-        granted = old < 0 ? 0 : (old < want ? old : want);
-        if (granted < want) atomicAdd(count, (uint32_t)(want - granted));
+        uint32_t seen = *(volatile uint32_t*)count;
+        while (true) {
+            granted = (int)seen < want ? (int)seen : want;
+            if (granted <= 0) { granted = 0; break; }
+            const uint32_t old = atomicCAS(count, seen, seen - (uint32_t)granted);
+            if (old == seen) break;
+            seen = old;
+        }
         if (granted) hb = atomicAdd(head, (uint32_t)granted);
     }
     base = __shfl(hb, 0, 64);
     return __shfl(granted, 0, 64);
 }
+
+// Pixel-ring cells carry the LAP of their position in the top byte of .y (1 .. 128; 0 = never written): a consumer knows which
+// lap it expects, so nobody has to clear a cell after reading it.  (A first version did clear cells, with a plain store that
+// nothing ordered against the NEXT lap's producer: on a workgroup with 64 pixels -- a 64-cell ring that turns over in
+// microseconds -- the late clear occasionally wiped a fresh entry or let a stale one be read twice, and one pixel of a 64x48
+// test frame came out different in one run of many.)
+#define ST_LAP_TAG(pos, cap) (((((pos) / (cap)) & 0x7Fu) + 1u) << 24)
+#define ST_LEFT_MASK 0x00FFFFFFu
 
 // pixel k of workgroup b's share: tile b + (k / 64) * workgroups of the owned tiles, lane k % 64 (false: outside the image)
 __device__ __forceinline__ bool st_pixel_of(const DevScene& S, uint32_t b, uint32_t nb, uint32_t k, uint32_t& px, uint32_t& py) {
@@ -222,7 +239,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
             st_begin_sample(S, W, g0 + v, idx, n_samples);
             s_wait[v] = 1u;
         } else if (valid) {
-            ring[v - ER_STREAM_SLOTS] = make_uint2(idx, n_samples);
+            ring[v - ER_STREAM_SLOTS] = make_uint2(idx, n_samples | ST_LAP_TAG(v - ER_STREAM_SLOTS, ring_cap));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         const unsigned long long m = __ballot(to_slot);
@@ -520,32 +537,34 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 if (mb) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the pixel's planes and RNG state first, then its entry
                     const uint32_t pos = st_reserve(&s_ctl[C_PX_TAIL], back);
-                    if (back) ring[pos & (ring_cap - 1u)] = make_uint2(done_idx, left_after);
+                    if (back) ring[pos & (ring_cap - 1u)] = make_uint2(done_idx, left_after | ST_LAP_TAG(pos, ring_cap));
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     if (lane == 0) atomicAdd(&s_ctl[C_PX_COUNT], (uint32_t)__popcll(mb));     // counted only once written
                 }
-                // take up to `want` entries: the count may go negative for a moment when several waves ask at once
+                // take up to `want` entries (exact count: a slot that has just put its pixel back always finds an entry unless
+                // another slot has taken it)
                 const unsigned long long mw = __ballot(want_pixel);
-                const int nw = __popcll(mw);
-                int granted = 0;
                 uint32_t hb = 0;
-                if (lane == 0) {
-                    const int old = (int)atomicSub(&s_ctl[C_PX_COUNT], (uint32_t)nw);
-                    granted = old < 0 ? 0 : (old < nw ? old : nw);
-                    if (granted < nw) atomicAdd(&s_ctl[C_PX_COUNT], (uint32_t)(nw - granted));
-                    if (granted) hb = atomicAdd(&s_ctl[C_PX_HEAD], (uint32_t)granted);
-                }
-                granted = __shfl(granted, 0, 64);
-                hb = __shfl(hb, 0, 64);
+                const int granted = st_take(&s_ctl[C_PX_COUNT], &s_ctl[C_PX_HEAD], __popcll(mw), hb);
                 const int rank = __popcll(mw & below);
                 if (want_pixel && rank < granted) {
-                    uint2* cell = ring + ((hb + (uint32_t)rank) & (ring_cap - 1u));
-                    // the cell's writer may still be on its way (positions are handed out before they are written)
+                    const uint32_t ppos = hb + (uint32_t)rank;
+                    const unsigned long long* cell = (const unsigned long long*)(ring + (ppos & (ring_cap - 1u)));
+                    const uint32_t want_tag = ST_LAP_TAG(ppos, ring_cap);
+                    // the cell's writer may still be on its way (positions are handed out before they are written): wait for THIS
+                    // lap's entry; pixel and count come in one 8-byte load
+                    unsigned long long w = 0;
                     uint32_t y = 0, guard = 0;
-                    while ((y = __hip_atomic_load(&cell->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0 && ++guard < (1u << 22)) __builtin_amdgcn_s_sleep(1);
+                    while (true) {
+                        w = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        y = (uint32_t)(w >> 32);
+                        if ((y & ~ST_LEFT_MASK) == want_tag) break;
+                        if (++guard >= (1u << 22)) { y = 0; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const uint32_t nidx = cell->x;
-                    *cell = make_uint2(0u, 0u);
+                    const uint32_t nidx = (uint32_t)w;
+                    y &= ST_LEFT_MASK;
                     if (y != 0) {
                         st_begin_sample(S, W, slot, nidx, y);
                         s_wait[ls] = 1u;
