@@ -210,31 +210,68 @@ def main():
         rm_.start_rendering(scene)
         return rm_
 
-    # (ER_BENCH_NO_PROFILE=1, diagnostic: time the region without the per-launch HIP events of ER_FLAG_PROFILE)
-    rm = manager(0 if os.environ.get("ER_BENCH_NO_PROFILE") == "1" else abi.FLAG_PROFILE)
-    accel = rm.accel_info()
-
     def sync_all():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        rm.render(args.warmup)
-    c_before = rm.counters()
-    sync_all()
-    t0 = time.perf_counter()
-    if args.per_step_launch:
-        for _ in range(args.steps):
-            rm.render(1, blocking=False)
-    else:
-        rm.render(args.steps, blocking=False)
-    kernel_ms = rm.wait()
-    prof = rm.profile()      # per-kernel device time of the timed region (HIP events on the streams the launches ran on)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    c_after = rm.counters()
+    def timed_region():
+        """warm-up + the timed region.  Library errors are caught around the library calls only, so that every rank still
+        reaches every barrier; the ranks then agree on whether the region succeeded."""
+        # (ER_BENCH_NO_PROFILE=1, diagnostic: time the region without the per-launch HIP events of ER_FLAG_PROFILE)
+        out = {"ok": 1, "error": None}
+        try:
+            out["rm"] = manager(0 if os.environ.get("ER_BENCH_NO_PROFILE") == "1" else abi.FLAG_PROFILE)
+            out["accel"] = out["rm"].accel_info()
+            if args.warmup > 0:
+                out["rm"].render(args.warmup)
+            out["c_before"] = out["rm"].counters()
+        except abi.ErError as e:
+            out["ok"], out["error"] = 0, str(e)
+        sync_all()
+        out["t0"] = time.perf_counter()
+        if out["ok"]:
+            try:
+                if args.per_step_launch:
+                    for _ in range(args.steps):
+                        out["rm"].render(1, blocking=False)
+                else:
+                    out["rm"].render(args.steps, blocking=False)
+                out["kernel_ms"] = out["rm"].wait()
+                out["prof"] = out["rm"].profile()   # per-kernel device time of the timed region (HIP events on the streams the launches ran on)
+                if os.environ.get("ER_BENCH_SIMULATE_STREAM_FAILURE") == "1" and sched_flag != abi.FLAG_WAVEFRONT:
+                    raise abi.ErError(-4, "simulated failure of the timed region (ER_BENCH_SIMULATE_STREAM_FAILURE)")   # tests the fallback below
+            except abi.ErError as e:
+                out["ok"], out["error"] = 0, str(e)
+        sync_all()
+        out["elapsed"] = time.perf_counter() - out["t0"]
+        if out["ok"]:
+            out["c_after"] = out["rm"].counters()
+        ok = out["ok"]
+        if dist is not None:
+            t = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        out["ok_all"] = ok
+        return out
+
+    region = timed_region()
+    schedule_fallback = None
+    if not region["ok_all"] and sched_flag in (0, abi.FLAG_STREAM):
+        # The streaming schedule ends a call with an error instead of hanging if a workgroup stops making progress (its
+        # watchdog).  The bench then measures the wavefront schedule and says so, rather than reporting nothing.
+        print(f"rank {rank}: timed region failed ({region['error']}); repeating it with the wavefront schedule", file=sys.stderr)
+        schedule_fallback = region["error"] or "another rank failed"
+        if region.get("rm") is not None:
+            region["rm"].close()
+        base_flags = abi.FLAG_WAVEFRONT | ext_flags | (abi.FLAG_GPU_BUILD if args.gpu_build else 0)
+        sched_flag = abi.FLAG_WAVEFRONT
+        region = timed_region()
+    if not region["ok_all"]:
+        raise RuntimeError(f"timed region failed: {region['error']}")
+    rm, accel, c_before, c_after = region["rm"], region["accel"], region["c_before"], region["c_after"]
+    kernel_ms, prof, elapsed = region["kernel_ms"], region["prof"], region["elapsed"]
     launches = args.steps if args.per_step_launch else 1
 
     samples = c_after["bounce_samples"] - c_before["bounce_samples"]
@@ -364,7 +401,7 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload}, max_bounces {max_bounces}, 1 step = 1 spp pass (config total {CONFIGS[args.config][2]} spp), seed 12345",
                        "sharding": f"8x8 pixel tiles, (tx+ty) % {shard_world}", "calls_in_timed_region": launches,
-                       "schedule": sched},
+                       "schedule": sched, "schedule_fallback": schedule_fallback},
             "paths_per_s": round(paths / elapsed, 1), "rays_per_s": round(rays / elapsed, 1),
             "mean_path_length": round(samples / max(1, paths), 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
