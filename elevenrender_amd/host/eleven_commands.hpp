@@ -302,7 +302,8 @@ private:
         if (const json::Value* v = j.if_contains("mis")) if (v->as_bool()) rp.flags |= ER_FLAG_MIS;
         if (const json::Value* v = j.if_contains("schedule")) {
             const std::string& s = v->as_string();
-            if (s == "wavefront") rp.flags |= ER_FLAG_WAVEFRONT;
+            if (s == "stream") rp.flags |= ER_FLAG_STREAM;
+            else if (s == "wavefront") rp.flags |= ER_FLAG_WAVEFRONT;
             else if (s == "fused") rp.flags |= ER_FLAG_FUSED;
             else if (s == "megakernel") rp.flags |= ER_FLAG_MEGAKERNEL;
             else if (s != "auto") throw std::runtime_error("config schedule '" + s + "' not recognised");
