@@ -529,6 +529,18 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     return ER_OK;
 }
 
+// The streaming kernel's waves give up instead of spinning forever if their workgroup makes no progress (er_stream.hip) and
+// say so in a status word.  Called with the scene's stream idle (after a wait or a read-back): an unfinished call must not pass
+// for a finished one.  The word stays set until the next er_render_begin.
+static int stream_status(ErScene* s, const char* who) {
+    if (!(s->params.flags & ER_FLAG_STREAM) || !s->stream_ctl) return ER_OK;
+    uint32_t st[2] = {0, 0};
+    HIP_TRY(hipMemcpy(st, s->stream_ctl, sizeof(st), hipMemcpyDeviceToHost));
+    if (st[1] != 0)
+        return fail(ER_ERR_STATE, std::string(who) + ": the streaming schedule stopped without finishing (watchdog status " + std::to_string(st[1]) + "); the planes are incomplete");
+    return ER_OK;
+}
+
 static int er_wait_impl(ErScene* s, float* elapsed_ms) {
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_wait: NULL scene");
     std::lock_guard<std::mutex> lk(s->mtx);
@@ -544,15 +556,7 @@ static int er_wait_impl(ErScene* s, float* elapsed_ms) {
         HIP_TRY(hipStreamSynchronize(s->stream));
     }
     if (elapsed_ms) *elapsed_ms = ms;
-    if ((s->params.flags & ER_FLAG_STREAM) && s->stream_ctl) {
-        // the streaming kernel's waves give up instead of spinning forever if their workgroup makes no progress (er_stream.hip)
-        uint32_t st[2] = {0, 0};
-        HIP_TRY(hipMemcpy(st, s->stream_ctl, sizeof(st), hipMemcpyDeviceToHost));
-        if (st[1] != 0) {
-            HIP_TRY(hipMemset(s->stream_ctl, 0, sizeof(st)));
-            return fail(ER_ERR_STATE, "er_wait: the streaming schedule stopped without finishing (watchdog status " + std::to_string(st[1]) + "); the planes are incomplete");
-        }
-    }
+    { int rc = stream_status(s, "er_wait"); if (rc != ER_OK) return rc; }
     s->profile = ErProfile{};
     s->profile.schedule = s->params.flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM);
     s->profile.concurrency = (s->params.flags & ER_FLAG_WAVEFRONT) ? (uint32_t)std::max<size_t>(1, s->wf.size()) : 1u;
@@ -598,7 +602,7 @@ static int read_back(ErScene* s, const void* src, void* dst, size_t bytes, const
     // ordered after everything enqueued so far: a sample-boundary snapshot, never a torn read
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return ER_OK;
+    return stream_status(s, who);
 }
 
 static int er_samples_done_impl(ErScene* s, uint32_t* out) {
