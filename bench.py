@@ -224,8 +224,10 @@ def main():
         try:
             out["rm"] = manager(0 if os.environ.get("ER_BENCH_NO_PROFILE") == "1" else abi.FLAG_PROFILE)
             out["accel"] = out["rm"].accel_info()
+            out["warmup_ms"] = None
             if args.warmup > 0:
-                out["rm"].render(args.warmup)
+                out["rm"].render(args.warmup, blocking=False)
+                out["warmup_ms"] = out["rm"].wait()       # device time of the warm-up call (one launch in the single-kernel schedules)
             out["c_before"] = out["rm"].counters()
         except abi.ErError as e:
             out["ok"], out["error"] = 0, str(e)
@@ -423,6 +425,9 @@ def main():
                          "achieved_per_launch": round(per_launch, 2),
                          "achieved_own_layout": round(achieved * layout_b / max(trace_b, 1.0), 2),
                          "avg_launch_ms": round(trace_ms_avg, 5), "algorithmic_bytes_per_launch": round(trace_b / t_launches, 1),
+                         # rocprofv3 --stats also sees the warm-up call: for the one-kernel-per-call schedules its row is
+                         # (warm-up launch, timed launch), i.e. MaxNs = avg_launch_ms and AverageNs = their mean
+                         "warmup_launch_ms": round(region["warmup_ms"], 3) if region.get("warmup_ms") is not None else None,
                          "trace_ms_total": round(prof["trace_ms"], 3), "shade_ms_total": round(prof["shade_ms"], 3),
                          "region_ms": round(kernel_ms, 3),
                          "whole_path_GBps": round(path_b / wall_s / 1e9, 2),
