@@ -314,9 +314,11 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         HIP_TRY(hipMemsetAsync(s->stream_ctl, 0, 2 * sizeof(uint32_t), s->stream));
         // the workgroups' pixel rings: (pixel, samples left) entries, one per pixel of the workgroup's share
         // (capacity rounded up to a power of two: positions are monotonic 32-bit counters and may wrap)
-        s->stream_ring_cap = 64u;
+        // at least 4096 cells: a lane reads the cell it has been granted within microseconds, and nothing may come round to
+        // that cell before it has (a lap of 4096 finished samples of one workgroup takes milliseconds)
+        s->stream_ring_cap = 4096u;
         while (s->stream_ring_cap < (uint32_t)((owned.size() + s->stream_blocks - 1) / s->stream_blocks) * 64u) s->stream_ring_cap <<= 1;
-        if ((rc = upload(s->d_ticket, nullptr, (size_t)s->stream_blocks * std::max<uint32_t>(s->stream_ring_cap, 64u) * 2, s->stream)) != ER_OK) return rc;
+        if ((rc = upload(s->d_ticket, nullptr, (size_t)s->stream_blocks * (size_t)s->stream_ring_cap * 2, s->stream)) != ER_OK) return rc;
         s->wf.clear();
     } else if (s->params.flags & ER_FLAG_WAVEFRONT) {
         // wavefront path state: one slot per owned pixel lane.
