@@ -383,6 +383,7 @@ def main():
         peak_measured = max(copy_gbs or 0.0, read_gbs or 0.0) or None
 
         traffic = None
+        traffic_source = None
         # HBM bytes from rocprofv3 PMC passes (tools/record_run.sh; the wavefront schedule's set was recorded with --schedule wavefront)
         tf = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}{'wf' if sched == 'wavefront' else ''}_pmc_traffic.json")
         if os.path.exists(tf) and world == 1 and args.config == "C2" and args.tris == 1_000_000 and not (args.width or args.height):
@@ -390,9 +391,11 @@ def main():
                 tj = json.load(open(tf))
                 if sched == "wavefront":
                     traffic = tj.get("er_wf_trace_hbm_bytes_per_launch")
+                    traffic_source = f"profiles/{os.path.basename(tf)}: PMC passes of an earlier run of this command, replayed (not measured in this run)"
                 elif sched == "stream" and tj.get("er_stream_kernel_hbm_bytes_per_step"):
                     # one launch of the streaming kernel runs all K steps of the call; the PMC passes measured bytes per step
                     traffic = tj["er_stream_kernel_hbm_bytes_per_step"] * args.steps / launches
+                    traffic_source = f"profiles/{os.path.basename(tf)}: bytes per step from PMC passes of an earlier run of this command x the steps of this launch, replayed (not measured in this run)"
             except Exception:
                 traffic = None
         value = samples / elapsed / 1e6
@@ -401,13 +404,16 @@ def main():
             "value": round(value, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed * 1e3 / args.steps, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # true = the default schedule's timed region ended in an error (its watchdog) and `value` was measured with the
+            # wavefront schedule instead: a correctness event of the product's default path; the process then exits with code 3
+            "degraded": schedule_fallback is not None,
             "config": {"workload": f"{workload}, max_bounces {max_bounces}, 1 step = 1 spp pass (config total {CONFIGS[args.config][2]} spp), seed 12345",
                        "sharding": f"8x8 pixel tiles, (tx+ty) % {shard_world}", "calls_in_timed_region": launches,
                        "schedule": sched, "schedule_fallback": schedule_fallback},
             "paths_per_s": round(paths / elapsed, 1), "rays_per_s": round(rays / elapsed, 1),
             "mean_path_length": round(samples / max(1, paths), 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          # the same counter bytes as a rate over the timed region: what the L2s asked of the fabric (Infinity-Cache hits
                          # are counted, MI355X_MICROARCH.md), against the spec peak and the peak measured in this job
                          # (wavefront: `traffic` is per trace launch of one pool -- the shade launches' bytes are not in it)
@@ -457,6 +463,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if schedule_fallback is not None:
+        sys.exit(3)      # the line above is a valid measurement of the fallback schedule, but the default one failed: not a success
 
 
 if __name__ == "__main__":

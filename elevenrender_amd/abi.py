@@ -153,6 +153,9 @@ class ErError(RuntimeError):
         self.code = code
 
 
+ABI_VERSION = 2     # include/eleven_hip.h ER_ABI_VERSION
+
+
 def load():
     """Load libeleven_hip.so and declare its prototypes.  Raises if it is not built."""
     global _lib
@@ -166,6 +169,8 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    if lib.er_abi_version() != ABI_VERSION:      # the structs below are filled completely by the library: a layout mismatch overwrites memory
+        raise ErError(ER_ERR_STATE, f"{LIB_PATH} has ABI version {lib.er_abi_version()}, this binding was written for {ABI_VERSION}: rebuild")
     _lib = lib
     return lib
 

@@ -282,8 +282,12 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         // small frames, which are launch-bound
         if (forced == 0) {
             const size_t px = owned.size() * 64;
+            int cus = 1;
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
+            cus = std::max(1, cus);
             if (px < 150000u) sched = ER_FLAG_FUSED;
             else if (px > 4000000u && s->tri_count > 4000000u) sched = ER_FLAG_WAVEFRONT;
+            else if ((owned.size() + (size_t)cus - 1) / (size_t)cus * 64u > ER_STREAM_MAX_RING) sched = ER_FLAG_WAVEFRONT;     // (beyond the streaming schedule's pixel rings)
             else sched = ER_FLAG_STREAM;
         }
         else if (forced & (forced - 1)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: more than one schedule flag");
@@ -308,16 +312,20 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
         if ((rc = upload(s->d_wf4, nullptr, slots * er_stream_record_bytes(lights_on) / sizeof(float4), s->stream)) != ER_OK) return rc;
         if ((rc = upload(s->d_wf1, nullptr, 2, s->stream)) != ER_OK) return rc;        // [1] status word
-        if ((rc = upload(s->d_spill, nullptr, (size_t)s->stream_blocks * 16 * ER_BVH_MAX_DEPTH * 64, s->stream)) != ER_OK) return rc;
+        if ((rc = upload(s->d_spill, nullptr, er_stream_spill_entries(s->stream_blocks), s->stream)) != ER_OK) return rc;
+        s->stream_pool = er_stream_pool_default() && wide_nodes < (1u << 24);      // (a context's stack entries keep node indices in 24 bits)
         s->stream_ctl = s->d_wf1.p;
         s->stream_lights = lights_on;
         HIP_TRY(hipMemsetAsync(s->stream_ctl, 0, 2 * sizeof(uint32_t), s->stream));
         // the workgroups' pixel rings: (pixel, samples left) entries, one per pixel of the workgroup's share
         // (capacity rounded up to a power of two: positions are monotonic 32-bit counters and may wrap)
-        // at least 4096 cells: a lane reads the cell it has been granted within microseconds, and nothing may come round to
-        // that cell before it has (a lap of 4096 finished samples of one workgroup takes milliseconds)
-        s->stream_ring_cap = 4096u;
+        // (no minimum beyond one tile: a producer that comes round to a cell whose entry has not been read yet waits for its
+        // reader, er_ring.h -- round 2 relied on "a lap of >= 4096 cells takes longer than a read")
+        s->stream_ring_cap = 64u;
         while (s->stream_ring_cap < (uint32_t)((owned.size() + s->stream_blocks - 1) / s->stream_blocks) * 64u) s->stream_ring_cap <<= 1;
+        if (s->stream_ring_cap > ER_STREAM_MAX_RING)
+            return fail(ER_ERR_INVALID_ARG, "er_render_begin: ER_FLAG_STREAM serves at most " + std::to_string((size_t)ER_STREAM_MAX_RING * s->stream_blocks) +
+                                                " owned pixels per rank; use ER_FLAG_WAVEFRONT (the automatic choice does)");
         if ((rc = upload(s->d_ticket, nullptr, (size_t)s->stream_blocks * (size_t)s->stream_ring_cap * 2, s->stream)) != ER_OK) return rc;
         s->wf.clear();
     } else if (s->params.flags & ER_FLAG_WAVEFRONT) {
@@ -470,7 +478,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
         er_launch_fused(s->dev, s->d_ticket.p, s->d_spill.p, n, count, s->fused_blocks, s->stream);
     } else if (s->params.flags & ER_FLAG_STREAM) {
         er_launch_stream(s->dev, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
-                         s->stream_blocks, s->stream_tracers, s->stream);
+                         s->stream_blocks, s->stream_tracers, s->stream_pool, s->stream);
     } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
         er_launch_render(s->dev, n, count, s->stream);
     }
@@ -534,7 +542,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
 // The streaming kernel's waves give up instead of spinning forever if their workgroup makes no progress (er_stream.hip) and
 // say so in a status word.  Called with the scene's stream idle (after a wait or a read-back): an unfinished call must not pass
 // for a finished one.  The word stays set until the next er_render_begin.
-static int stream_status(ErScene* s, const char* who) {
+int er_scene_stream_status(ErScene* s, const char* who) {
     if (!(s->params.flags & ER_FLAG_STREAM) || !s->stream_ctl) return ER_OK;
     uint32_t st[2] = {0, 0};
     HIP_TRY(hipMemcpy(st, s->stream_ctl, sizeof(st), hipMemcpyDeviceToHost));
@@ -558,7 +566,7 @@ static int er_wait_impl(ErScene* s, float* elapsed_ms) {
         HIP_TRY(hipStreamSynchronize(s->stream));
     }
     if (elapsed_ms) *elapsed_ms = ms;
-    { int rc = stream_status(s, "er_wait"); if (rc != ER_OK) return rc; }
+    { int rc = er_scene_stream_status(s, "er_wait"); if (rc != ER_OK) { s->prof_used = 0; return rc; } }   // (the profiling window ends with the call either way)
     s->profile = ErProfile{};
     s->profile.schedule = s->params.flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM);
     s->profile.concurrency = (s->params.flags & ER_FLAG_WAVEFRONT) ? (uint32_t)std::max<size_t>(1, s->wf.size()) : 1u;
@@ -604,7 +612,7 @@ static int read_back(ErScene* s, const void* src, void* dst, size_t bytes, const
     // ordered after everything enqueued so far: a sample-boundary snapshot, never a torn read
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return stream_status(s, who);
+    return er_scene_stream_status(s, who);
 }
 
 static int er_samples_done_impl(ErScene* s, uint32_t* out) {
@@ -671,7 +679,7 @@ static int er_state_export_impl(ErScene* s, void* dst, uint64_t bytes) {
     p += npx * sizeof(uint32_t);
     HIP_TRY(hipMemcpyAsync(p, s->d_rng.p, npx * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return ER_OK;
+    return er_scene_stream_status(s, "er_state_export");     // never checkpoint planes the library itself calls incomplete
 }
 
 static int er_state_import_impl(ErScene* s, const void* src, uint64_t bytes) {
@@ -728,7 +736,7 @@ static int er_denoise_impl(ErScene* s, uint32_t levels, float colour_sigma) {
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return ER_OK;
+    return er_scene_stream_status(s, "er_denoise");
 }
 
 static int er_read_samples_impl(ErScene* s, uint32_t* dst) {
@@ -757,7 +765,7 @@ static int er_pack_owned_impl(ErScene* s, int pass, void* dev_dst) {
     er_launch_pack(s->dev, s->d_owned.p, s->dev.owned_tile_count, pass, dev_dst, s->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(s->stream));
-    return ER_OK;
+    return er_scene_stream_status(s, "er_pack_owned");
 }
 
 static int er_unpack_owned_impl(ErScene* s, int pass, uint32_t src_rank, const void* dev_src) {

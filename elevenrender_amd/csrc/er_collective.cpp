@@ -205,7 +205,7 @@ static int er_gather_pass_impl(ErScene* s, int pass, ErComm* c, uint32_t root) {
         if (rc != ER_OK) return rc;
         if (rc2 != ER_OK) return rc2;
         HIP_TRY(hipStreamSynchronize(st));   // `mine` is freed on return
-        return ER_OK;
+        return er_scene_stream_status(s, "er_gather_pass");   // (what was sent is incomplete if the streaming schedule stopped early)
     }
     // root: one receive buffer per peer, all receives in ONE group (seven xGMI links side by side), then the scatters
     std::vector<ScopedDevBuf<float4>> in(c->world);
@@ -237,7 +237,7 @@ static int er_gather_pass_impl(ErScene* s, int pass, ErComm* c, uint32_t root) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     for (uint32_t r = 0; r < c->world; r++) if (r != root) s->unpacked[pass].insert(r);
-    return ER_OK;
+    return er_scene_stream_status(s, "er_gather_pass");
 }
 
 extern "C" {

@@ -14,6 +14,14 @@
 #include "er_cdf.h"
 #include "er_math.h"
 
+// ISA region marks for tools/isa_budget.py: with -DER_ISA_MARKS every ER_MARK("name") leaves an assembler comment in the
+// device assembly (hipcc -S) at that point of the instruction stream; the product build compiles them to nothing.
+#ifdef ER_ISA_MARKS
+#define ER_MARK(name) asm volatile("; ER_MARK " name ::: "memory")
+#else
+#define ER_MARK(name) ((void)0)
+#endif
+
 #define ER_TILE 8                 // 8x8 pixel tile = one 64-lane wavefront
 #define ER_STACK ER_BVH_MAX_DEPTH
 

@@ -1,0 +1,132 @@
+// er_ring.h -- the bounded multi-producer / multi-consumer rings of the CU-resident streaming schedule (er_stream.hip),
+// written once for the device (LDS words, LDS atomics) and for the host-thread model of the protocol
+// (tests/native/ring_model.cpp, compiled with -DER_RING_HOST_MODEL and run under ThreadSanitizer on the CPU).
+//
+// Why this file exists: the first three ring protocols of the streaming schedule each rested on a timing argument ("a lap of
+// the ring takes longer than a lane needs to read the cell it was granted") and two of them failed on hardware.  The rule
+// here is the bounded-queue rule of Vyukov's MPMC ring: every cell carries the LAP of the position it serves and whether it is
+// FULL, producers and consumers both CHECK the cell before they touch it and nobody ever clears anything:
+//
+//     cell = lap(19 bits) | full(1 bit) | payload(12 bits)          all cells start as lap 0, empty
+//     producer of position p:  wait until cell == (lap(p), empty)   -> store (lap(p), full, payload)
+//     consumer of position p:  wait until cell == (lap(p), full, *) -> take payload, store (lap(p) + 1, empty)
+//
+// A cell can therefore only walk the chain (L, empty) -> (L, full) -> (L + 1, empty) -> ...: a producer that comes round to a
+// cell whose previous entry has been granted but not yet read WAITS for that reader (it is on its way: a granted lane reads
+// its cell unconditionally), and a consumer that is granted a position whose producer has reserved but not yet written it
+// waits for that writer.  No entry can be lost, duplicated or read from the wrong lap, whatever the interleaving; the only
+// number that could alias is the 19-bit lap, i.e. a lane would have to stall between two adjacent instructions while its ring
+// turns 524 288 times.  (Positions are 32-bit and wrap; capacities are powers of two, so `pos & (cap - 1)` and `pos >> log2(cap)`
+// stay consistent across the wrap.)
+//
+// Counters of a ring (three words): TAIL = positions reserved by producers, COUNT = entries published (written) and not yet
+// granted, HEAD = positions granted to consumers.  A producer wave reserves n positions with one add to TAIL, its lanes put
+// their cells, then it adds n to COUNT; a consumer wave is granted min(want, COUNT) entries with a compare-and-swap on COUNT
+// (exact at every instant: never below zero) and takes that many positions from HEAD.  COUNT counts entries, not positions:
+// because reservations complete out of order, the cells at the granted positions need not be the ones whose writers have
+// published -- that is what the per-cell wait is for.
+//
+// The pixel ring of a workgroup lives in HBM (its capacity scales with the frame) and keeps its own cell format (pixel,
+// samples left | lap tag: er_stream.hip); its "previous entry has been read" check is one bit per cell in LDS
+// (er_bits_acquire / er_bits_release below): the producer sets the bit before it writes the cell and waits while it is
+// still set, the consumer clears it after it has read the cell.
+#pragma once
+#include <stdint.h>
+
+#ifdef ER_RING_HOST_MODEL
+#include <thread>
+#define ER_RING_FN static inline
+ER_RING_FN uint32_t er_ring_load(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+ER_RING_FN void er_ring_store(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+ER_RING_FN uint32_t er_ring_add(uint32_t* p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
+ER_RING_FN uint32_t er_ring_or(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_ACQ_REL); }
+ER_RING_FN uint32_t er_ring_and(uint32_t* p, uint32_t v) { return __atomic_fetch_and(p, v, __ATOMIC_ACQ_REL); }
+ER_RING_FN uint32_t er_ring_cas(uint32_t* p, uint32_t expect, uint32_t desired) {
+    __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+    return expect;      // (the value found, like atomicCAS)
+}
+ER_RING_FN void er_ring_pause() { std::this_thread::yield(); }
+#else
+#include <hip/hip_runtime.h>
+#define ER_RING_FN __device__ __forceinline__
+// LDS words: volatile accesses are single ds_read / ds_write instructions, LDS operations of one wave execute in order and
+// all waves of the workgroup see one LDS
+ER_RING_FN uint32_t er_ring_load(const uint32_t* p) { return *(const volatile uint32_t*)p; }
+ER_RING_FN void er_ring_store(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
+ER_RING_FN uint32_t er_ring_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+ER_RING_FN uint32_t er_ring_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+ER_RING_FN uint32_t er_ring_and(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
+ER_RING_FN uint32_t er_ring_cas(uint32_t* p, uint32_t expect, uint32_t desired) { return atomicCAS(p, expect, desired); }
+ER_RING_FN void er_ring_pause() { __builtin_amdgcn_s_sleep(1); }
+#endif
+
+#define ER_RING_PAYLOAD_BITS 12
+#define ER_RING_PAYLOAD_MASK ((1u << ER_RING_PAYLOAD_BITS) - 1u)
+#define ER_RING_FULL (1u << ER_RING_PAYLOAD_BITS)
+#define ER_RING_LAP_SHIFT (ER_RING_PAYLOAD_BITS + 1)
+enum { ER_RING_TAIL = 0, ER_RING_COUNT = 1, ER_RING_HEAD = 2, ER_RING_WORDS = 3 };
+// A wait that outlasts this many polls means the protocol itself is broken (a writer or reader that never comes): the
+// caller raises the launch's status word instead of hanging.  Far longer than any wait a correct run can see.
+#define ER_RING_GUARD (1u << 22)
+
+ER_RING_FN uint32_t er_ring_lap(uint32_t pos, uint32_t cap_log2) { return (pos >> cap_log2) << ER_RING_LAP_SHIFT; }
+
+// ---- per lane ----
+// producer of position `pos` (reserved for this lane): false = guard expired (status word, never in a correct run)
+ER_RING_FN bool er_ring_put(uint32_t* cells, uint32_t cap_log2, uint32_t pos, uint32_t payload) {
+    uint32_t* cell = cells + (pos & ((1u << cap_log2) - 1u));
+    const uint32_t empty = er_ring_lap(pos, cap_log2);
+    uint32_t guard = 0;
+    while (er_ring_load(cell) != empty) {        // the previous lap's entry is still being read
+        if (++guard >= ER_RING_GUARD) return false;
+        er_ring_pause();
+    }
+    er_ring_store(cell, empty | ER_RING_FULL | (payload & ER_RING_PAYLOAD_MASK));
+    return true;
+}
+// consumer of position `pos` (granted to this lane)
+ER_RING_FN bool er_ring_get(uint32_t* cells, uint32_t cap_log2, uint32_t pos, uint32_t& payload) {
+    uint32_t* cell = cells + (pos & ((1u << cap_log2) - 1u));
+    const uint32_t full = er_ring_lap(pos, cap_log2) | ER_RING_FULL;
+    uint32_t v, guard = 0;
+    while (((v = er_ring_load(cell)) & ~ER_RING_PAYLOAD_MASK) != full) {      // its writer is on its way
+        if (++guard >= ER_RING_GUARD) { payload = 0; return false; }
+        er_ring_pause();
+    }
+    payload = v & ER_RING_PAYLOAD_MASK;
+    er_ring_store(cell, er_ring_lap(pos + (1u << cap_log2), cap_log2));        // (lap + 1, empty): free for the next lap's writer
+    return true;
+}
+
+// ---- per wave (one lane calls; the caller broadcasts the result) ----
+ER_RING_FN uint32_t er_ring_reserve(uint32_t* ctl, uint32_t n) { return er_ring_add(&ctl[ER_RING_TAIL], n); }
+ER_RING_FN void er_ring_publish(uint32_t* ctl, uint32_t n) { er_ring_add(&ctl[ER_RING_COUNT], n); }
+// grants min(want, COUNT) entries; `base` = the first granted position.  The compare-and-swap keeps COUNT exact at every
+// instant (a subtract-then-restore lets it dip below zero while several waves ask at once: the fault of the second protocol).
+ER_RING_FN uint32_t er_ring_grant(uint32_t* ctl, uint32_t want, uint32_t& base) {
+    uint32_t seen = er_ring_load(&ctl[ER_RING_COUNT]), granted = 0;
+    base = 0;
+    while (true) {
+        granted = seen < want ? seen : want;
+        if (granted == 0 || granted > 0x7fffffffu) return 0;
+        const uint32_t found = er_ring_cas(&ctl[ER_RING_COUNT], seen, seen - granted);
+        if (found == seen) break;
+        seen = found;
+    }
+    base = er_ring_add(&ctl[ER_RING_HEAD], granted);
+    return granted;
+}
+
+// ---- one "occupied" bit per cell of a ring whose cells live elsewhere (the HBM pixel ring) ----
+// producer, before it writes cell `idx`: waits while the previous lap's entry of that cell has not been read
+ER_RING_FN bool er_bits_acquire(uint32_t* bits, uint32_t idx) {
+    const uint32_t m = 1u << (idx & 31u);
+    uint32_t guard = 0;
+    while (er_ring_or(&bits[idx >> 5], m) & m) {
+        if (++guard >= ER_RING_GUARD) return false;
+        er_ring_pause();
+    }
+    return true;
+}
+// consumer, after it has read cell `idx`
+ER_RING_FN void er_bits_release(uint32_t* bits, uint32_t idx) { er_ring_and(&bits[idx >> 5], ~(1u << (idx & 31u))); }

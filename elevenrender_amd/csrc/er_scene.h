@@ -181,6 +181,7 @@ struct ErScene {
     DevBuf<uint32_t> d_guide, d_ticket;
     uint32_t fused_blocks = 0;
     uint32_t stream_blocks = 0, stream_tracers = 0, stream_ring_cap = 0;     // streaming schedule (er_stream.hip): workgroups; tracer waves of the 16
+    bool stream_pool = false;                           //   tracer: the context pool (er_stream.hip) or the first one
     bool stream_lights = false;                         //   slot records carry the point-light query's line
     uint32_t* stream_ctl = nullptr;                     //   [0] pixel ticket, [1] status word
     std::vector<WfState> wf;              // slot pools (see er_render_begin)
@@ -229,6 +230,10 @@ struct ErScene {
         timing_open = false;
     }
 };
+
+// ER_OK unless the streaming schedule's watchdog ended a call early (er_api.cpp); call with the scene's stream idle and its
+// mutex held.  Every entry point that hands planes out (read-backs, snapshot, gather, pack, denoise) ends with it.
+extern "C" __attribute__((visibility("hidden"))) int er_scene_stream_status(ErScene* s, const char* who);   // (library-internal)
 
 namespace erh {
 

@@ -1,6 +1,7 @@
 // er_stream.h -- launch wrapper of the CU-resident streaming schedule (er_stream.hip, ER_FLAG_STREAM).
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <stddef.h>
 #include <stdint.h>
 
 struct DevScene;
@@ -12,11 +13,16 @@ struct WfState;
                                   // rings of more slots take is worth more as tree levels)
 #endif
 
+#define ER_STREAM_MAX_RING 32768u  // cells of a workgroup's pixel ring at most (one "entry read" bit per cell in LDS): a rank may own
+                                  // up to 256 x 32768 = 8.4 M pixels under this schedule (a 4K frame), beyond that er_render_begin takes the wavefront one
+
 // records: slots * er_stream_record_bytes(lights) bytes (slots = blocks * ER_STREAM_SLOTS; lights: the scene uses the point-light
-// extension, whose queries take a third line per slot); spill: 16 * ER_BVH_MAX_DEPTH * 64 uint2 entries per workgroup; ring:
-// blocks * ring_cap uint2 entries (the workgroups' pixel rings; ring_cap = a power of two >= 64 * ceil(owned tiles / blocks)); status: one
-// word, 0 unless a wave's watchdog fired.
+// extension, whose queries take a third line per slot); spill: er_stream_spill_entries(blocks) uint2 entries; ring:
+// blocks * ring_cap uint2 entries (the workgroups' pixel rings; ring_cap = a power of two >= 64 * ceil(owned tiles / blocks) and
+// <= ER_STREAM_MAX_RING); status: one word, 0 unless a wave's watchdog or a ring guard fired; pool: the context-pool tracer (er_stream.hip).
 void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, void* ring, uint32_t ring_cap, uint32_t* status,
-                      uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream);
+                      uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, bool pool, hipStream_t stream);
 uint32_t er_stream_record_bytes(bool lights);
+size_t er_stream_spill_entries(uint32_t blocks);
+bool er_stream_pool_default();      // which tracer: ER_STREAM_POOL=1 the context pool, 0 the first one (A/B knob)
 hipError_t er_probe_stream(const char** which);

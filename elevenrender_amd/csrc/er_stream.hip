@@ -11,64 +11,108 @@
 //     pixel, samples left) and takes the pixel at its head: a pixel's samples are one RNG stream and must run one after
 //     the other, but with single samples as the unit all of a workgroup's pixels advance side by side and finish
 //     together (with whole pixels as the unit the call ended in a long tail of last pixels).  Slot state lives in HBM
-//     with the wavefront schedule's fields (one record per slot, StState below); slots, ring and the planes of the
-//     workgroup's pixels are only ever touched
+//     (one record per slot, StState below); slots, ring and the planes of the workgroup's pixels are only ever touched
 //     by waves of that workgroup -- i.e. of one CU, which share the vector L1 -- so workgroup-scope release/acquire (a wait
 //     for the wave's own stores) is all the ordering needed;
-//   * the two kinds of waves feed each other through two rings in LDS: rays to trace (closest-hit and shadow queries) and
-//     slots to shade.  A per-slot counter in LDS holds the number of rays of the slot still in flight; the tracer that
-//     finishes the last one appends the slot to the shade ring.  Producers write their cells and then add to the ring's
-//     count of written entries; a consumer wave takes min(wanted, count) entries with one LDS atomic (st_take), so a ring
-//     position is only ever held for an entry that exists, and no lane waits for another lane's ray;
-//   * there is no launch boundary between bounces and therefore no tail in which a few long rays hold a launch open: a
-//     tracer lane that finishes a ray takes the next one from the ring, whatever bounce or sample it belongs to.
+//   * shader waves and tracer waves feed each other through two rings in LDS: rays to trace (closest-hit and shadow queries)
+//     and slots to shade.  A per-slot counter in LDS holds the number of rays of the slot still in flight; the tracer that
+//     finishes the last one appends the slot to the shade ring;
+//   * every ring is the bounded queue of er_ring.h: cells carry (lap, full, payload), producers and consumers CHECK the cell
+//     they were given and nobody clears anything, so no entry can be lost, duplicated or read from the wrong lap whatever the
+//     interleaving -- no timing assumption (the host-thread model of the same functions, tests/native/ring_model.cpp, runs
+//     them with tiny capacities under ThreadSanitizer);
+//   * there is no launch boundary between bounces and therefore no tail in which a few long rays hold a launch open.
+//
+// Two tracers (template parameter POOL):
+//   POOL = false  the first one (round 2): a tracer lane OWNS a ray from the ring to its last step, state in registers,
+//                 er_wf_trace's loop: every iteration issues the node block AND the triangle block for the whole wave,
+//                 although 85 % / 29 % of the busy lanes want them (lane utilisation 0.52, profiles/r02_pmc_valu.csv);
+//   POOL = true   the CONTEXT POOL (round 3): a ray in flight is a 96-byte context in LDS (ray constants, node group,
+//                 triangle group, candidates, a 6-entry stack); tracer waves are stateless executors that take 64 context
+//                 ids from the NODE queue or from the TRIANGLE queue, run only that block for 64 lanes that all want it,
+//                 write the contexts back and route each id to the queue of its next step.  New rays enter in the idle
+//                 lanes of a node batch.  DESIGN.md section 5 has the instruction budget of both.
 //
 // Every wave leaves its loop when the workgroup's last slot has retired (s_ctl[C_DONE]); a wave that sees no progress for
-// ~0.2 s raises the status word and ends the workgroup (it cannot hang).
+// ~0.2 s, or whose ring wait outlasts ER_RING_GUARD polls, raises the status word and ends the workgroup (it cannot hang).
 #include <cstdlib>
+#include <type_traits>
 #include "er_device.h"
 #include "er_kernels.h"
 #include "er_wavefront.h"
 #include "er_trav.h"
 #include "er_shade.h"
 #include "er_stream.h"
+#include "er_ring.h"
 
 using namespace erd;
 
 namespace {
 
-// ring capacities (powers of two, with room to spare).  ray ring: >= 3 rays per slot (2 without the point-light extension);
-// shade ring: >= one entry per slot
-#define ST_POW2_GE(x) ((x) <= 1024u ? 1024u : (x) <= 2048u ? 2048u : (x) <= 4096u ? 4096u : (x) <= 8192u ? 8192u : 16384u)
-#define ST_RQ_CAP_OF(ext) ST_POW2_GE(((ext) ? 3u : 2u) * ER_STREAM_SLOTS + 768u)
-#define ST_SQ_CAP ST_POW2_GE(ER_STREAM_SLOTS + 1024u)
-#define ST_KIND_SHIFT 13         // ray-ring entry = local slot | kind << 13: 0 closest hit, 1 HDRI shadow query, 2 point-light query
-#define ST_FIN 0x100u            // s_wait flag: when its rays are done the slot is only finalised (ER_WF_FINALIZE_ONLY)
-#define ST_SQ_FIN 0x10000u       // the same flag in a shade-ring entry
+#define ST_SLOT_BITS 10          // ring payloads: local slot (10 bits) | kind or flag (2 bits) = ER_RING_PAYLOAD_BITS
+static_assert(ER_STREAM_SLOTS <= (1u << ST_SLOT_BITS), "a local slot must fit the ring payload");
+#define ST_SLOT_MASK ((1u << ST_SLOT_BITS) - 1u)
+// ray-ring entry = local slot | kind << 10: 0 closest hit, 1 HDRI shadow query, 2 point-light query;
+// shade-ring entry = local slot | fin << 10 (fin: the slot is only finalised, ER_WF_FINALIZE_ONLY)
+#define ST_FIN 0x100u            // the same flag in s_wait
+// ring capacities (log2).  With the checked cells a full ring only makes its producers wait (shader waves for the tracers
+// to drain the ray ring -- which they do whatever the shaders are doing -- never the other way round: the shade ring holds
+// a slot at most once, so ER_STREAM_SLOTS cells can never be full), so capacities are a tuning matter, not a safety margin.
+#define ST_RQ_LOG2_OF(pool) ((pool) ? 11u : 12u)
+#define ST_SQ_LOG2 10u
+static_assert((1u << ST_SQ_LOG2) >= ER_STREAM_SLOTS, "the shade ring must hold every slot once");
+// a wave's reservation (<= 3 x 64 entries) must fit the ring several times over (a reservation longer than the ring would wait for
+// readers of its own unpublished entries), and the camera rays of all slots go in before the waves start
+static_assert((1u << ST_RQ_LOG2_OF(true)) >= ER_STREAM_SLOTS && (1u << ST_RQ_LOG2_OF(true)) >= 4u * 192u, "ray ring too small");
 #ifndef ST_THREADS
 #define ST_THREADS 1024          // 16 waves per CU: four per SIMD, 128 VGPRs each
 #endif
-// north_star: "top BVH levels staged in LDS".  Every workgroup keeps the first ER_STREAM_TOP_NODES wide nodes in LDS (the
-// tree is stored breadth-first: 585 = levels 0-3, 47 KB) and the tracer lanes whose node is one of them read it with
-// ds_read_b128 instead of five global loads: 9 of a ray's 21 node visits on C2.  Measured on C2 (1024 slots): 0 nodes 1240,
-// 73 -> 1274, 256 -> 1286, 585 -> 1330, 800 -> 1331 Msamples/s (profiles/r02_ab_top_levels_in_lds.log).  The reads are
-// issued AFTER the step's global loads have arrived, straight into the registers those would have filled: a first version
-// that fetched them early into registers of their own spilled the tracer loop and ran 2.6x slower.
+// north_star: "top BVH levels staged in LDS".  Every workgroup keeps the first wide nodes in LDS (the tree is stored
+// breadth-first: 585 = levels 0-3, 47 KB) and the tracer lanes whose node is one of them read it with ds_read_b128 instead of
+// five global loads: 9 of a ray's 21 node visits on C2.  Measured on C2 with the first tracer: 0 nodes 1240, 73 -> 1274,
+// 256 -> 1286, 585 -> 1330, 800 -> 1331 Msamples/s (profiles/r02_ab_top_levels_in_lds.log).  The context pool needs LDS for
+// its contexts and keeps the first 400.
 #ifndef ER_STREAM_TOP_NODES
 #define ER_STREAM_TOP_NODES 585
 #endif
-#define ST_NONE 0xFFFFFFFFu
+#ifndef ER_POOL_TOP_NODES
+#define ER_POOL_TOP_NODES 400
+#endif
 #define ST_MAX_TRACERS 12
-enum { C_RQ_HEAD = 0, C_RQ_TAIL, C_RQ_COUNT, C_SQ_HEAD, C_SQ_TAIL, C_SQ_COUNT, C_LIVE, C_DONE, C_PX_HEAD, C_PX_TAIL, C_PX_COUNT, C_INIT, C_WORDS };
+enum { C_LIVE = 0, C_DONE, C_INIT, C_WORDS };
 #ifndef ST_IDLE_SLEEP
 #define ST_IDLE_SLEEP 16         // s_sleep argument (x 64 cycles) of a wave that found nothing to do (4 .. 48 measured: no difference)
 #endif
 #ifndef ST_BATCH_SLEEP
-#define ST_BATCH_SLEEP 8         // ... of a shader wave waiting for a fuller batch
+#define ST_BATCH_SLEEP 8         // ... of a wave waiting for a fuller batch
 #endif
 #define ST_WATCHDOG 300000u      // idle polls (>= 1000 cycles each) without any ring activity in the workgroup before a wave gives up
 #define WF_PENDING_BIT 0x10000u  // per-slot flags in reduc.w, as in er_wavefront.hip: bounce (bits 0-15) | pending HDRI shadow query
 #define WF_LPENDING_BIT 0x20000u //   | pending point-light query
+// status word bits (er_wait turns any of them into ER_ERR_STATE): 1 tracer watchdog, 2 shader watchdog, 4 pixel ring, 8 shade
+// ring, 16 ray ring, 32 context queues -- the last four mean a ring wait outlasted its guard, which no correct run can see
+#define ST_ERR_PIXEL 4u
+#define ST_ERR_SHADE 8u
+#define ST_ERR_RAY 16u
+#define ST_ERR_CTX 32u
+// the pixel ring's "previous entry has been read" bits (er_ring.h): one per cell, so ring_cap <= ER_STREAM_MAX_RING (er_api.cpp checks)
+#define ST_PXBITS_WORDS (ER_STREAM_MAX_RING / 32u)
+
+// ---- the context pool (POOL = true) ----
+#define PL_CTX_LOG2 10u
+#define PL_NCTX (1u << PL_CTX_LOG2)      // contexts (rays in flight) per workgroup; ids fit the ring payload
+#define PL_STACK 6                       // stack entries of a context in LDS (C2: the stack is never deeper; deeper levels: HBM)
+#define PL_PIECES 6                      // 16-byte pieces per context:
+//   [0] idir.xyz, U            [1] noi.xyz, meta        [2] ng_base, ng_bits, tg_base, tg_mask      [3] lo0, lo1, s0, s1
+//   [4..5] the stack: six entries (ng_base | nmask << 24), then their six imask bytes
+// meta = oct7 (bits 0-2) | sp (3-7) | shadow (8) | overflow (9) | kind (10-11) | local slot (12-21)
+#define PL_META_SP_SHIFT 3
+#define PL_META_SP_MASK 31u
+#define PL_META_SHADOW (1u << 8)
+#define PL_META_OVERFLOW (1u << 9)
+#define PL_META_KIND_SHIFT 10
+#define PL_META_SLOT_SHIFT 12
+static_assert(ER_BVH_MAX_DEPTH <= 32, "sp is kept in 5 bits");
 
 __device__ __forceinline__ unsigned st_wave_sum(unsigned v) {
 #pragma unroll
@@ -76,7 +120,7 @@ __device__ __forceinline__ unsigned st_wave_sum(unsigned v) {
     return v;
 }
 
-// wave-aggregated reservation of ring positions (LDS counter): returns this lane's position (valid only if `want`)
+// wave-aggregated reservation on a plain LDS counter: returns this lane's rank-ordered value (valid only if `want`)
 __device__ __forceinline__ uint32_t st_reserve(uint32_t* counter, bool want) {
     const unsigned long long mask = __ballot(want);
     if (mask == 0) return 0;
@@ -88,10 +132,32 @@ __device__ __forceinline__ uint32_t st_reserve(uint32_t* counter, bool want) {
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
+// a wave appends the payloads of its `want` lanes to a ring: one reservation, every lane puts its own cell (waiting, in
+// theory, for the previous lap's reader), then the entries are published.  All lanes of the wave call.
+template <uint32_t LOG2>
+__device__ __forceinline__ void st_push(uint32_t* cells, uint32_t* ctl, bool want, uint32_t payload, uint32_t* status, uint32_t err) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return;
+    const unsigned lane = threadIdx.x & 63;
+    const uint32_t n = (uint32_t)__popcll(m);
+    uint32_t base = 0;
+    if (lane == 0) base = er_ring_reserve(ctl, n);
+    base = __shfl(base, 0, 64);
+    if (want && !er_ring_put(cells, LOG2, base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), payload)) atomicOr(status, err);
+    if (lane == 0) er_ring_publish(ctl, n);      // after the cells: the LDS operations of a wave execute in order
+}
+
+// a wave is granted min(want, published entries) positions of a ring (all lanes call; wave-uniform result)
+__device__ __forceinline__ uint32_t st_take(uint32_t* ctl, uint32_t want, uint32_t& base) {
+    uint32_t granted = 0, hb = 0;
+    if ((threadIdx.x & 63) == 0 && want > 0) granted = er_ring_grant(ctl, want, hb);
+    base = __shfl(hb, 0, 64);
+    return __shfl(granted, 0, 64);
+}
+
 // The slot records of the wavefront schedule (er_wavefront.h: the same fields with the same meaning), laid out slot by slot.
 //   * ONE base pointer: the kernel holds tracer and shader code side by side and both keep many uniform values in scalar
-//     registers; twenty plane pointers are forty of them (a first build reloaded spilled scalars 85 times per iteration of
-//     the tracer loop).  A field's address is base + a 32-bit byte offset (scalar-base addressing form);
+//     registers; twenty plane pointers are forty of them.  A field's address is base + a 32-bit byte offset;
 //   * records, not planes: the shade ring delivers slots in the order their rays finish, so a wave's 64 slots are scattered
 //     over the workgroup's slots; with one plane per field every 16-byte access pulled in the records of seven other
 //     slots (L2 hit rate 47 %, 1.5x the fabric reads of the wavefront schedule); a slot's fields now share its own lines.
@@ -128,41 +194,15 @@ struct StState {
     __device__ __forceinline__ float4& aov_b(uint32_t i) const { return fld<float4, 160>(i); }
     __device__ __forceinline__ float4& c_vis(uint32_t i) const { return fld2<float4, 176, 304>(i); }
     __device__ __forceinline__ float4& c_occ(uint32_t i) const { return fld2<float4, 192, 320>(i); }
+    // the (origin, direction) pair a tracer reads for ray kind 0 / 1 / 2 of slot g: two adjacent 16-byte pieces
+    __device__ __forceinline__ const float4* ray_pair(uint32_t g, uint32_t kind) const {
+        return (const float4*)(base + (size_t)(g * stride + (kind == 0u ? 0u : (kind == 1u ? 32u : 256u))));
+    }
 };
 
-// Taking entries from a ring (all lanes of the wave call; wave-uniform result).  `count` = entries that have been WRITTEN
-// and not yet handed out; the wave takes min(want, count) of them -- `granted`, at positions base .. base + granted - 1 -- with
-// a compare-and-swap, so the count is exact at every instant.  Two earlier protocols, both caught by tests:
-//   * idle lanes reserved positions AHEAD of the producers and polled them: a lane whose wave then did not poll for a few
-//     hundred microseconds had its cell overwritten after the ring wrapped, the ray was lost and the workgroup never
-//     finished (the watchdog's first catch);
-//   * subtract-then-restore (count may dip below zero while several waves ask at once): harmless for the LDS rings, but in
-//     the pixel ring a slot that had just put its pixel back could be refused during another wave's dip, retire, and -- if
-//     every other slot retired too -- leave the pixel in the ring: one pixel of a small frame one sample short, once in
-//     ~50 runs.
-__device__ __forceinline__ int st_take(uint32_t* count, uint32_t* head, int want, uint32_t& base) {
-    int granted = 0;
-    uint32_t hb = 0;
-    if ((threadIdx.x & 63) == 0 && want > 0) {
-        uint32_t seen = *(volatile uint32_t*)count;
-        while (true) {
-            granted = (int)seen < want ? (int)seen : want;
-            if (granted <= 0) { granted = 0; break; }
-            const uint32_t old = atomicCAS(count, seen, seen - (uint32_t)granted);
-            if (old == seen) break;
-            seen = old;
-        }
-        if (granted) hb = atomicAdd(head, (uint32_t)granted);
-    }
-    base = __shfl(hb, 0, 64);
-    return __shfl(granted, 0, 64);
-}
-
-// Pixel-ring cells carry the LAP of their position in the top byte of .y (1 .. 128; 0 = never written): a consumer knows which
-// lap it expects, so nobody has to clear a cell after reading it.  (A first version did clear cells, with a plain store that
-// nothing ordered against the NEXT lap's producer: on a workgroup with 64 pixels -- a 64-cell ring that turns over in
-// microseconds -- the late clear occasionally wiped a fresh entry or let a stale one be read twice, and one pixel of a 64x48
-// test frame came out different in one run of many.)
+// Pixel-ring cells carry the LAP of their position in the top byte of .y (1 .. 128; 0 = never written): a consumer waits for the
+// entry of ITS lap.  Whether the previous lap's entry of a cell has been read is one bit per cell in LDS (er_bits_acquire /
+// er_bits_release, er_ring.h): a producer that comes round to an unread cell waits for its reader instead of overwriting it.
 #define ST_LAP_TAG(pos, cap) (((((pos) / (cap)) & 0x7Fu) + 1u) << 24)
 #define ST_LEFT_MASK 0x00FFFFFFu
 
@@ -193,37 +233,48 @@ __device__ __forceinline__ void st_begin_sample(const DevScene& S, const StState
     W.left(g) = left;
 }
 
+// what a finished traversal leaves in the slot's record (closest: winner + second candidate; shadow: verdict + candidates)
+__device__ __forceinline__ void st_write_result(const StState& W, uint32_t rec, bool shadow, bool occluded, bool overflow, int s0, int s1) {
+    if (shadow) {
+        W.occluded(rec) = occluded ? 1 : (overflow ? 3 : (s0 >= 0 ? 2 : 0));     // a certain occluder ends the query at once
+        W.occ_a(rec) = s0;
+        W.occ_b(rec) = s1;
+    } else {
+        W.hit(rec) = s0 >= 0 ? s0 : s1;
+        W.hit2(rec) = overflow ? -2 : ((s0 >= 0 && s1 >= 0) ? s1 : -1);
+    }
+}
+
 }  // namespace
 
-template <bool COUNT, bool EXT>
+template <bool COUNT, bool EXT, bool POOL>
 __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StState W, uint2* ring_base, uint32_t ring_cap, uint32_t* status,
                                                           uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min) {
-    __shared__ uint2 s_stack[ST_MAX_TRACERS * WF_LDS_STACK * 64];
-    constexpr uint32_t ST_RQ_CAP = ST_RQ_CAP_OF(EXT);
-    __shared__ uint32_t s_rq[ST_RQ_CAP];
-    __shared__ uint32_t s_sq[ST_SQ_CAP];
+    constexpr uint32_t RQ_LOG2 = ST_RQ_LOG2_OF(POOL);
+    constexpr uint32_t TOP_NODES = POOL ? ER_POOL_TOP_NODES : ER_STREAM_TOP_NODES;
+    __shared__ uint32_t s_rq[1u << RQ_LOG2];
+    __shared__ uint32_t s_sq[1u << ST_SQ_LOG2];
     __shared__ uint32_t s_wait[ER_STREAM_SLOTS];
-    __shared__ uint32_t s_ctl[C_WORDS];
-#if ER_STREAM_TOP_NODES > 0
-    __shared__ float4 s_top[ER_STREAM_TOP_NODES * ER_NODE8_PIECES];
-    for (uint32_t i = threadIdx.x; i < ER_STREAM_TOP_NODES * ER_NODE8_PIECES; i += ST_THREADS)
+    __shared__ uint32_t s_pxbits[ST_PXBITS_WORDS];
+    __shared__ uint32_t s_rq_ctl[ER_RING_WORDS], s_sq_ctl[ER_RING_WORDS], s_px_ctl[ER_RING_WORDS], s_ctl[C_WORDS];
+    __shared__ float4 s_top[TOP_NODES * ER_NODE8_PIECES];
+    for (uint32_t i = threadIdx.x; i < TOP_NODES * ER_NODE8_PIECES; i += ST_THREADS)
         s_top[i] = i < S.node8_count * ER_NODE8_PIECES ? S.nodes8[i] : make_float4(0, 0, 0, 0);
-#endif
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t g0 = blockIdx.x * ER_STREAM_SLOTS;          // this workgroup's first slot
-    volatile uint32_t* v_rq = s_rq;
-    volatile uint32_t* v_sq = s_sq;
     volatile uint32_t* v_ctl = s_ctl;
     const unsigned long long below = (1ull << lane) - 1ull;
 
-    // ---- start: empty rings, then every slot takes a pixel and queues its first camera ray ----
-    for (uint32_t i = threadIdx.x; i < ST_RQ_CAP; i += ST_THREADS) s_rq[i] = 0;
-    for (uint32_t i = threadIdx.x; i < ST_SQ_CAP; i += ST_THREADS) s_sq[i] = 0;
+    // ---- start: empty rings (every cell = lap 0, empty), then every slot takes a pixel and queues its first camera ray ----
+    for (uint32_t i = threadIdx.x; i < (1u << RQ_LOG2); i += ST_THREADS) s_rq[i] = 0;
+    for (uint32_t i = threadIdx.x; i < (1u << ST_SQ_LOG2); i += ST_THREADS) s_sq[i] = 0;
+    for (uint32_t i = threadIdx.x; i < ST_PXBITS_WORDS; i += ST_THREADS) s_pxbits[i] = 0;
+    if (threadIdx.x < ER_RING_WORDS) { s_rq_ctl[threadIdx.x] = 0; s_sq_ctl[threadIdx.x] = 0; s_px_ctl[threadIdx.x] = 0; }
     if (threadIdx.x < C_WORDS) s_ctl[threadIdx.x] = 0;
     __syncthreads();
     // this workgroup's pixels in the order of its tiles: the first ER_STREAM_SLOTS valid ones start in the slots, the others
-    // wait in the pixel ring (entry = pixel, samples left; .y == 0 marks an empty cell)
+    // wait in the pixel ring (entry = pixel, samples left | lap tag; tag 0 marks a cell never written)
     uint2* ring = ring_base + (size_t)blockIdx.x * ring_cap;
     for (uint32_t s = threadIdx.x; s < ER_STREAM_SLOTS; s += ST_THREADS) s_wait[s] = 0;
     for (uint32_t k = threadIdx.x; k < ring_cap; k += ST_THREADS) ring[k] = make_uint2(0u, 0u);
@@ -239,164 +290,434 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
             st_begin_sample(S, W, g0 + v, idx, n_samples);
             s_wait[v] = 1u;
         } else if (valid) {
-            ring[v - ER_STREAM_SLOTS] = make_uint2(idx, n_samples | ST_LAP_TAG(v - ER_STREAM_SLOTS, ring_cap));
+            const uint32_t pos = v - ER_STREAM_SLOTS;      // (< ring_cap: lap 0 of a ring nobody reads yet)
+            atomicOr(&s_pxbits[pos >> 5], 1u << (pos & 31u));
+            ring[pos] = make_uint2(idx, n_samples | ST_LAP_TAG(pos, ring_cap));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         const unsigned long long m = __ballot(to_slot);
         if (m) {
             if (lane == (int)(__ffsll((long long)m) - 1)) atomicAdd(&s_ctl[C_LIVE], (uint32_t)__popcll(m));
-            const uint32_t pos = st_reserve(&s_ctl[C_RQ_TAIL], to_slot);
-            if (to_slot) s_rq[pos & (ST_RQ_CAP - 1u)] = v + 1u;
-            if (lane == 0) atomicAdd(&s_ctl[C_RQ_COUNT], (uint32_t)__popcll(m));
+            st_push<RQ_LOG2>(s_rq, s_rq_ctl, to_slot, v, status, ST_ERR_RAY);      // kind 0: the camera ray
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t nv = s_ctl[C_INIT];
         const uint32_t in_ring = nv > ER_STREAM_SLOTS ? nv - ER_STREAM_SLOTS : 0u;
-        s_ctl[C_PX_HEAD] = 0;
-        s_ctl[C_PX_TAIL] = in_ring;
-        s_ctl[C_PX_COUNT] = in_ring;
+        s_px_ctl[ER_RING_HEAD] = 0;
+        s_px_ctl[ER_RING_TAIL] = in_ring;
+        s_px_ctl[ER_RING_COUNT] = in_ring;
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_ctl[C_LIVE] == 0) s_ctl[C_DONE] = 1;
-    __syncthreads();
-    // from here on the waves run their own loops: NO workgroup barrier below this line
 
     unsigned c_rays = 0, c_nodes = 0, c_tris = 0;
     unsigned c_paths = 0, c_bounce = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;
     unsigned c_wsteps = 0, c_busy = 0, c_nl = 0, c_tl = 0;
-    uint2* spill = W.spill + (size_t)(blockIdx.x * 16u + wave) * (ER_STACK * 64) + lane;
 
-    if (wave < tracers) {
-        // =========================== tracer: er_wf_trace's loop, fed from the ray ring ===========================
-        uint2* stack = s_stack + (size_t)wave * (WF_LDS_STACK * 64) + lane;
-        Trav T;
-        trav_begin(T, f3s(0), f3(0, 0, 1), false, -1, 0.0f);
-        bool busy = false;
-        uint32_t ls = 0, kind = 0, rec = 0;   // the ray in hand: local slot, kind, index of its records (g, or g + W.slots)
-        uint32_t idle = 0, progress = 0;
-        while (true) {
-            // idle lanes take rays from the ring; skipped while fewer than refill_min lanes are idle (it costs the whole wave ~40
-            // instructions and, when rays are taken, a pair of dependent loads) or the ring has nothing written
-            const unsigned long long bm0 = __ballot(busy);
-            if ((64u - (unsigned)__popcll(bm0) >= refill_min || bm0 == 0) && (int)v_ctl[C_RQ_COUNT] > 0) {
-                uint32_t hb = 0;
-                const int granted = st_take(&s_ctl[C_RQ_COUNT], &s_ctl[C_RQ_HEAD], 64 - __popcll(bm0), hb);
-                const bool take = !busy && __popcll(~bm0 & below) < granted;
-                if (granted > 0) {
-                    uint32_t v = 0;
-                    if (take) {
-                        volatile uint32_t* cell = v_rq + ((hb + (uint32_t)__popcll(~bm0 & below)) & (ST_RQ_CAP - 1u));
-                        uint32_t guard = 0;
-                        while ((v = *cell) == 0 && ++guard < (1u << 22)) __builtin_amdgcn_s_sleep(1);   // (its writer is on its way)
-                        *cell = 0;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    if (take && v != 0) {
-                        const uint32_t e = v - 1u;
-                        ls = e & ((1u << ST_KIND_SHIFT) - 1u);
-                        kind = e >> ST_KIND_SHIFT;
-                        rec = g0 + ls + (kind == 2u ? W.slots : 0u);
-                        const bool shadow = kind != 0u;
-                        const float4 ro = shadow ? W.sh_o(rec) : W.ray_o(rec);
-                        const float4 rd = shadow ? W.sh_d(rec) : W.ray_d(rec);
-                        trav_begin(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), shadow, shadow ? __builtin_bit_cast(int, ro.w) : -1,
-                                   shadow ? rd.w : __builtin_inff());
-                        c_rays++;
-                        busy = true;
-                    } else if (take) {
-                        atomicOr(status, 16u);      // (cannot happen: a granted entry was never written)
-                    }
-                }
-            }
-            const unsigned long long bm = __ballot(busy);
-            if (bm == 0) {
-                if (v_ctl[C_DONE]) break;
-                __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
-                const uint32_t pr = v_ctl[C_RQ_TAIL] + v_ctl[C_SQ_TAIL];
-                if (pr != progress) { progress = pr; idle = 0; }
-                if (++idle > ST_WATCHDOG) {
-                    if (lane == 0) { atomicOr(status, 1u); s_ctl[C_DONE] = 1; }
-                    break;
-                }
-                continue;
-            }
-            idle = 0;
-            bool finished = false, do_step = false;
-            TravStep st;
-            st.node = false; st.tri = false; st.two = false; st.tslot = 0; st.noff = 0; st.toff = 0;
-            if (busy) {
-                if (S.node_count != 0) do_step = trav_choose(T, S, stack, spill, st);
-                finished = !do_step;
-            }
-            if (COUNT) {
-                c_wsteps++;
-                c_busy += (unsigned)__popcll(bm);
-                c_nl += (unsigned)__popcll(__ballot(st.node));
-                c_tl += (unsigned)__popcll(__ballot(st.tri));
-            }
-            TravData D;
-#if ER_STREAM_TOP_NODES > 0
-            {
-                const bool top = st.node && st.noff < (uint32_t)(ER_STREAM_TOP_NODES * ER_NODE8_PIECES);
-                TravStep sg = st;
-                if (top) sg.node = false;          // (these lanes' node loads go to the shared dummy address)
-                trav_fetch(S, sg, D);
-                if (top) { const float4* q = s_top + st.noff; D.n0 = q[0]; D.n1 = q[1]; D.n2 = q[2]; D.n3 = q[3]; D.n4 = q[4]; }
-            }
-#else
-            trav_fetch(S, st, D);
-#endif
-            if (busy) {
-                if (do_step) {
-                    if (trav_apply<COUNT>(T, S, st, D, c_nodes, c_tris)) {
-                        W.occluded(rec) = 1;   // a certain occluder ends the shadow query
-                        finished = true;
-                    }
-                } else if (T.shadow) {
-                    W.occluded(rec) = T.overflow ? 3 : (T.s0 >= 0 ? 2 : 0);
-                }
-                if (finished) {
-                    if (T.shadow) {
-                        W.occ_a(rec) = T.s0;
-                        W.occ_b(rec) = T.s1;
-                    } else {
-                        W.hit(rec) = T.s0 >= 0 ? T.s0 : T.s1;
-                        W.hit2(rec) = T.overflow ? -2 : ((T.s0 >= 0 && T.s1 >= 0) ? T.s1 : -1);
-                    }
-                    busy = false;
-                }
-            }
-            // results out, then the slot's in-flight count; the tracer that takes it to zero hands the slot to the shaders
-            if (__ballot(finished)) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                bool last = false;
-                uint32_t old = 0;
-                if (finished) {
-                    old = atomicSub(&s_wait[ls], 1u);
-                    last = (old & 0xFFu) == 1u;
-                }
-                if (__ballot(last)) {
-                    const unsigned long long ml = __ballot(last);
-                    const uint32_t pos = st_reserve(&s_ctl[C_SQ_TAIL], last);
-                    if (last) s_sq[pos & (ST_SQ_CAP - 1u)] = (ls | ((old & ST_FIN) ? ST_SQ_FIN : 0u)) + 1u;
-                    if (lane == 0) atomicAdd(&s_ctl[C_SQ_COUNT], (uint32_t)__popcll(ml));      // (after the cells: LDS is in order per wave)
-                }
-            }
+    if constexpr (POOL) {
+        // =========================== tracers of the context pool ===========================
+        __shared__ float4 s_ctx[PL_NCTX * PL_PIECES];
+        __shared__ uint32_t s_nq[PL_NCTX], s_tq[PL_NCTX], s_fl[PL_NCTX];
+        __shared__ uint32_t s_nq_ctl[ER_RING_WORDS], s_tq_ctl[ER_RING_WORDS], s_fl_ctl[ER_RING_WORDS];
+        // node queue and triangle queue empty; every context id in the free list (lap 0, full)
+        for (uint32_t i = threadIdx.x; i < PL_NCTX; i += ST_THREADS) { s_nq[i] = 0; s_tq[i] = 0; s_fl[i] = ER_RING_FULL | i; }
+        if (threadIdx.x < ER_RING_WORDS) {
+            s_nq_ctl[threadIdx.x] = 0; s_tq_ctl[threadIdx.x] = 0;
+            s_fl_ctl[threadIdx.x] = threadIdx.x == ER_RING_HEAD ? 0u : PL_NCTX;      // TAIL = COUNT = PL_NCTX
         }
-    } else {
+        __syncthreads();
+        // from here on the waves run their own loops: NO workgroup barrier below this line
+        if (wave < tracers) {
+            uint32_t idle = 0, spins = 0, progress = 0;
+            while (true) {
+                ER_MARK("pool_loop_top");
+                // ---- what is there to do?  a full batch of triangle steps, else a full batch of node steps, else whatever is
+                //      there (after a short wait for a fuller batch); new rays ride in the idle lanes of a node batch ----
+                const uint32_t tq = er_ring_load(&s_tq_ctl[ER_RING_COUNT]), nq = er_ring_load(&s_nq_ctl[ER_RING_COUNT]);
+                const uint32_t rq = er_ring_load(&s_rq_ctl[ER_RING_COUNT]), fl = er_ring_load(&s_fl_ctl[ER_RING_COUNT]);
+                const uint32_t fresh = rq < fl ? rq : fl;
+                if (tq + nq + fresh == 0) {
+                    if (v_ctl[C_DONE]) break;
+                    __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
+                    const uint32_t pr = er_ring_load(&s_rq_ctl[ER_RING_TAIL]) + er_ring_load(&s_sq_ctl[ER_RING_TAIL]) + er_ring_load(&s_nq_ctl[ER_RING_TAIL]) +
+                                        er_ring_load(&s_tq_ctl[ER_RING_TAIL]);
+                    if (pr != progress) { progress = pr; idle = 0; }
+                    if (++idle > ST_WATCHDOG) {
+                        if (lane == 0) { atomicOr(status, 1u); s_ctl[C_DONE] = 1; }
+                        break;
+                    }
+                    continue;
+                }
+                idle = 0;
+                const uint32_t best = tq > nq + fresh ? tq : nq + fresh;
+                if (best < refill_min && spins < 8u) {     // a fuller batch costs the same instructions: wait a little for one
+                    spins++;
+                    __builtin_amdgcn_s_sleep(ST_BATCH_SLEEP);
+                    continue;
+                }
+                spins = 0;
+                const bool tri_mode = tq >= 64u || (tq > 0u && tq >= nq + fresh);
+
+                bool have = false, fin = false, to_nq = false, to_tq = false;
+                uint32_t id = 0, meta = 0;
+                int r_s0 = -1, r_s1 = -1;
+                bool r_occluded = false;
+                if (tri_mode) {
+                    // =============== a batch of TRIANGLE steps ===============
+                    ER_MARK("pool_tri_take");
+                    uint32_t hb = 0;
+                    const uint32_t granted = st_take(s_tq_ctl, 64u, hb);
+                    if (granted == 0) continue;          // another wave was quicker
+                    have = (uint32_t)lane < granted;
+                    if (have && !er_ring_get(s_tq, PL_CTX_LOG2, hb + (uint32_t)lane, id)) { atomicOr(status, ST_ERR_CTX); have = false; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    float4* cx = s_ctx + (size_t)id * PL_PIECES;
+                    Trav T;
+                    TravStep st;
+                    st.node = false; st.tri = false; st.two = false; st.tslot = 0; st.noff = 0; st.toff = 0;
+                    uint32_t ng_bits = 0, tg_base = 0, tg_mask = 0, ls = 0, kind = 0;
+                    if (have) {
+                        const float4 p2 = cx[2];
+                        meta = __builtin_bit_cast(uint32_t, cx[1].w);
+                        ng_bits = __builtin_bit_cast(uint32_t, p2.y);
+                        tg_base = __builtin_bit_cast(uint32_t, p2.z);
+                        tg_mask = __builtin_bit_cast(uint32_t, p2.w);
+                        ls = (meta >> PL_META_SLOT_SHIFT) & ST_SLOT_MASK;
+                        kind = (meta >> PL_META_KIND_SHIFT) & 3u;
+                        // the triangle part of trav_choose: pending bit i is triangle number popcount(present bits below i) of the
+                        // group; a second pending triangle rides along when it is the very next record in memory
+                        const uint32_t m = tg_mask & 0xffffu, present = tg_mask >> 16;
+                        st.tri = m != 0;
+                        const unsigned i = __ffs(m | 0x10000u) - 1;
+                        const uint32_t rest = m & (m - 1u);
+                        const unsigned j = __ffs(rest | 0x10000u) - 1;
+                        st.two = rest != 0 && (present & ((1u << j) - 1u) & ~((2u << i) - 1u)) == 0;
+                        tg_mask = (tg_mask & 0xffff0000u) | (st.two ? (rest & (rest - 1u)) : rest);
+                        st.tslot = tg_base + __popc(present & ((1u << i) - 1u));
+                        st.toff = S.tri_base_pieces + st.tslot * 3u;
+                    }
+                    if (COUNT) { c_wsteps++; c_busy += granted; c_tl += (unsigned)__popcll(__ballot(st.tri)); }
+                    TravData D;
+                    float4 ro, rd;
+                    {
+                        const float4* pt = S.nodes8 + (st.tri ? st.toff : 0u);
+                        const float4* pt2 = (st.tri && st.two) ? pt : S.nodes8;
+                        const float4* pr = have ? W.ray_pair(g0 + ls, kind) : S.nodes8;
+                        ER_MARK("pool_tri_fetch");
+                        asm volatile("global_load_dwordx4 %0, %8, off\n\t"
+                                     "global_load_dwordx4 %1, %8, off offset:16\n\t"
+                                     "global_load_dwordx4 %2, %8, off offset:32\n\t"
+                                     "global_load_dwordx4 %3, %9, off offset:48\n\t"
+                                     "global_load_dwordx4 %4, %9, off offset:64\n\t"
+                                     "global_load_dwordx4 %5, %9, off offset:80\n\t"
+                                     "global_load_dwordx4 %6, %10, off\n\t"
+                                     "global_load_dwordx4 %7, %10, off offset:16\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(D.a), "=&v"(D.b4), "=&v"(D.c), "=&v"(D.dd), "=&v"(D.e4), "=&v"(D.f4), "=&v"(ro), "=&v"(rd)
+                                     : "v"(pt), "v"(pt2), "v"(pr)
+                                     : "memory");
+                    }
+                    ER_MARK("pool_tri_apply");
+                    if (have) {
+                        const bool shadow = (meta & PL_META_SHADOW) != 0;
+                        const float4 p3 = cx[3];
+                        T.o = f3(ro.x, ro.y, ro.z);
+                        T.d = f3(rd.x, rd.y, rd.z);
+                        T.shadow = shadow;
+                        T.skip = shadow ? __builtin_bit_cast(int, ro.w) : -1;
+                        T.limit = shadow ? rd.w : __builtin_inff();
+                        T.U = cx[0].w;
+                        T.lo0 = p3.x; T.lo1 = p3.y;
+                        T.s0 = __builtin_bit_cast(int, p3.z); T.s1 = __builtin_bit_cast(int, p3.w);
+                        T.overflow = (meta & PL_META_OVERFLOW) != 0;
+                        r_occluded = trav_apply_tri<COUNT>(T, S, st, D, c_tris);
+                        cx[0].w = T.U;
+                        cx[3] = make_float4(T.lo0, T.lo1, __builtin_bit_cast(float, T.s0), __builtin_bit_cast(float, T.s1));
+                        cx[2].w = __builtin_bit_cast(float, tg_mask);
+                        if (T.overflow && !(meta & PL_META_OVERFLOW)) {
+                            meta |= PL_META_OVERFLOW;
+                            cx[1].w = __builtin_bit_cast(float, meta);
+                        }
+                        r_s0 = T.s0; r_s1 = T.s1;
+                        const uint32_t sp = (meta >> PL_META_SP_SHIFT) & PL_META_SP_MASK;
+                        to_tq = !r_occluded && (tg_mask & 0xffffu) != 0;
+                        to_nq = !r_occluded && !to_tq && ((ng_bits & 0xffu) != 0 || sp > 0);
+                        fin = !to_tq && !to_nq;
+                    }
+                } else {
+                    // =============== a batch of NODE steps, new rays in its idle lanes ===============
+                    ER_MARK("pool_node_take");
+                    uint32_t hbn = 0, hbf = 0, hbr = 0;
+                    const uint32_t granted = st_take(s_nq_ctl, 64u, hbn);
+                    uint32_t got_ctx = 0, got_ray = 0;
+                    if (granted < 64u && fresh > 0) {
+                        const uint32_t want = (64u - granted) < rq ? (64u - granted) : rq;
+                        got_ctx = st_take(s_fl_ctl, want, hbf);
+                        if (got_ctx) got_ray = st_take(s_rq_ctl, got_ctx, hbr);
+                    }
+                    const uint32_t rnk = (uint32_t)lane - granted;                 // rank among the lanes that took a free context
+                    const bool has_ctx = (uint32_t)lane >= granted && rnk < got_ctx;
+                    bool init = has_ctx && rnk < got_ray;
+                    have = (uint32_t)lane < granted;
+                    uint32_t e = 0;
+                    if (have && !er_ring_get(s_nq, PL_CTX_LOG2, hbn + (uint32_t)lane, id)) { atomicOr(status, ST_ERR_CTX); have = false; }
+                    if (has_ctx && !er_ring_get(s_fl, PL_CTX_LOG2, hbf + rnk, id)) { atomicOr(status, ST_ERR_CTX); init = false; }
+                    if (init && !er_ring_get(s_rq, RQ_LOG2, hbr + rnk, e)) { atomicOr(status, ST_ERR_RAY); init = false; }
+                    // (a context taken for a ray that another wave got first goes straight back)
+                    st_push<PL_CTX_LOG2>(s_fl, s_fl_ctl, has_ctx && !init, id, status, ST_ERR_CTX);
+                    if (granted + got_ray == 0) continue;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    float4* cx = s_ctx + (size_t)id * PL_PIECES;
+                    uint32_t* stk = (uint32_t*)(cx + 4);
+                    volatile uint8_t* stk_im = (volatile uint8_t*)(stk + PL_STACK);
+                    uint2* spill = W.spill + ((size_t)blockIdx.x * PL_NCTX + id) * ER_STACK;
+                    uint32_t sp = 0, oct7 = 0, noff = 0;
+                    bool top = false;
+                    const uint32_t ls_new = e & ST_SLOT_MASK, kind_new = e >> ST_SLOT_BITS;
+                    ER_MARK("pool_node_choose");
+                    if (have) {
+                        const float4 p2 = cx[2];
+                        meta = __builtin_bit_cast(uint32_t, cx[1].w);
+                        uint32_t ng_base = __builtin_bit_cast(uint32_t, p2.x), ng_bits = __builtin_bit_cast(uint32_t, p2.y);
+                        sp = (meta >> PL_META_SP_SHIFT) & PL_META_SP_MASK;
+                        oct7 = meta & 7u;
+                        // the node part of trav_choose: pop when the current group is used up, take its nearest child, push the rest
+                        if ((ng_bits & 0xffu) == 0 && sp > 0) {
+                            sp--;
+                            if (sp < PL_STACK) {
+                                const uint32_t en = *(volatile uint32_t*)(stk + sp);
+                                ng_base = en & 0xffffffu;
+                                ng_bits = (en >> 24) | ((uint32_t)stk_im[sp] << 8);
+                            } else {
+                                const uint2 g = spill[sp - PL_STACK];
+                                ng_base = g.x;
+                                ng_bits = g.y;
+                            }
+                        }
+                        uint32_t nmask = ng_bits & 0xffu;
+                        const uint32_t imask = (ng_bits >> 8) & 0xffu;
+                        const unsigned b = 31 - __clz(nmask | 1u);
+                        nmask &= ~(1u << b);
+                        const unsigned s8 = b ^ oct7;
+                        const uint32_t child = ng_base + __popc(imask & ((1u << s8) - 1u));
+                        if (nmask) {                       // siblings still to visit: one stack entry for the whole group
+                            if (sp < PL_STACK) {
+                                *(volatile uint32_t*)(stk + sp) = ng_base | (nmask << 24);
+                                stk_im[sp] = (uint8_t)imask;
+                            } else {
+                                spill[sp - PL_STACK] = make_uint2(ng_base, nmask | (imask << 8));
+                            }
+                            sp++;
+                        }
+                        noff = child * (uint32_t)ER_NODE8_PIECES;
+                        top = noff < (uint32_t)(TOP_NODES * ER_NODE8_PIECES);
+                    }
+                    if (COUNT) { c_wsteps++; c_busy += granted + got_ray; c_nl += granted; }
+                    TravData D;
+                    {
+                        const float4* pn = have ? (S.nodes8 + (top ? 0u : noff)) : (init ? W.ray_pair(g0 + ls_new, kind_new) : S.nodes8);
+                        ER_MARK("pool_node_fetch");
+                        asm volatile("global_load_dwordx4 %0, %5, off\n\t"
+                                     "global_load_dwordx4 %1, %5, off offset:16\n\t"
+                                     "global_load_dwordx4 %2, %5, off offset:32\n\t"
+                                     "global_load_dwordx4 %3, %5, off offset:48\n\t"
+                                     "global_load_dwordx4 %4, %5, off offset:64\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(D.n0), "=&v"(D.n1), "=&v"(D.n2), "=&v"(D.n3), "=&v"(D.n4)
+                                     : "v"(pn)
+                                     : "memory");
+                        if (top) { const float4* q = s_top + noff; D.n0 = q[0]; D.n1 = q[1]; D.n2 = q[2]; D.n3 = q[3]; D.n4 = q[4]; }
+                    }
+                    ER_MARK("pool_node_apply");
+                    if (have) {
+                        Trav T;
+                        TravStep st;
+                        st.node = true; st.tri = false; st.two = false; st.tslot = 0; st.noff = noff; st.toff = 0;
+                        const float4 p0 = cx[0], p1 = cx[1];
+                        T.idir = f3(p0.x, p0.y, p0.z);
+                        T.U = p0.w;
+                        T.noi = f3(p1.x, p1.y, p1.z);
+                        T.oct7 = oct7;
+                        trav_apply_node<COUNT>(T, S, st, D, c_nodes);
+                        cx[2] = make_float4(__builtin_bit_cast(float, T.ng_base), __builtin_bit_cast(float, T.ng_bits), __builtin_bit_cast(float, T.tg_base),
+                                            __builtin_bit_cast(float, T.tg_mask));
+                        meta = (meta & ~(PL_META_SP_MASK << PL_META_SP_SHIFT)) | (sp << PL_META_SP_SHIFT);
+                        cx[1].w = __builtin_bit_cast(float, meta);
+                        to_tq = (T.tg_mask & 0xffffu) != 0;
+                        to_nq = !to_tq && ((T.ng_bits & 0xffu) != 0 || sp > 0);
+                        fin = !to_tq && !to_nq;
+                        if (fin) {
+                            const float4 p3 = cx[3];
+                            r_s0 = __builtin_bit_cast(int, p3.z);
+                            r_s1 = __builtin_bit_cast(int, p3.w);
+                        }
+                    } else if (init) {
+                        // a new ray: trav_begin, written into the context; its first node step (the root, in LDS) is the next hop
+                        const bool shadow = kind_new != 0u;
+                        Trav T;
+                        trav_begin(T, f3(D.n0.x, D.n0.y, D.n0.z), f3(D.n1.x, D.n1.y, D.n1.z), shadow, shadow ? __builtin_bit_cast(int, D.n0.w) : -1,
+                                   shadow ? D.n1.w : __builtin_inff());
+                        meta = T.oct7 | (shadow ? PL_META_SHADOW : 0u) | (kind_new << PL_META_KIND_SHIFT) | (ls_new << PL_META_SLOT_SHIFT);
+                        cx[0] = make_float4(T.idir.x, T.idir.y, T.idir.z, T.U);
+                        cx[1] = make_float4(T.noi.x, T.noi.y, T.noi.z, __builtin_bit_cast(float, meta));
+                        cx[2] = make_float4(__builtin_bit_cast(float, T.ng_base), __builtin_bit_cast(float, T.ng_bits), __builtin_bit_cast(float, 0u),
+                                            __builtin_bit_cast(float, 0u));
+                        cx[3] = make_float4(0.0f, 0.0f, __builtin_bit_cast(float, -1), __builtin_bit_cast(float, -1));
+                        c_rays++;
+                        have = true;
+                        to_nq = S.node_count != 0;
+                        fin = !to_nq;          // (an empty scene: every query ends at once, nothing hit)
+                    }
+                }
+                // =============== route: finished rays hand their slot on, the others go to the queue of their next step ===============
+                ER_MARK("pool_route");
+                const uint32_t ls = (meta >> PL_META_SLOT_SHIFT) & ST_SLOT_MASK;
+                if (fin) {
+                    const uint32_t kind = (meta >> PL_META_KIND_SHIFT) & 3u;
+                    st_write_result(W, g0 + ls + (kind == 2u ? W.slots : 0u), (meta & PL_META_SHADOW) != 0, r_occluded, (meta & PL_META_OVERFLOW) != 0, r_s0, r_s1);
+                }
+                // the contexts (LDS) and the results (HBM) are written: now publish
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (__ballot(fin)) {
+                    bool last = false;
+                    uint32_t old = 0;
+                    if (fin) {
+                        old = atomicSub(&s_wait[ls], 1u);
+                        last = (old & 0xFFu) == 1u;
+                    }
+                    st_push<ST_SQ_LOG2>(s_sq, s_sq_ctl, last, ls | ((old & ST_FIN) ? (1u << ST_SLOT_BITS) : 0u), status, ST_ERR_SHADE);
+                    st_push<PL_CTX_LOG2>(s_fl, s_fl_ctl, fin, id, status, ST_ERR_CTX);
+                }
+                st_push<PL_CTX_LOG2>(s_tq, s_tq_ctl, to_tq, id, status, ST_ERR_CTX);
+                st_push<PL_CTX_LOG2>(s_nq, s_nq_ctl, to_nq, id, status, ST_ERR_CTX);
+                ER_MARK("pool_iter_end");
+            }
+            ER_MARK("pool_loop_end");
+        }
+    }
+    if constexpr (!POOL) {
+        __shared__ uint2 s_stack[ST_MAX_TRACERS * WF_LDS_STACK * 64];
+        __syncthreads();
+        // from here on the waves run their own loops: NO workgroup barrier below this line
+        if (wave < tracers) {
+            // =========================== tracer: er_wf_trace's loop, fed from the ray ring ===========================
+            uint2* spill = W.spill + (size_t)(blockIdx.x * 16u + wave) * (ER_STACK * 64) + lane;
+            uint2* stack = s_stack + (size_t)wave * (WF_LDS_STACK * 64) + lane;
+            Trav T;
+            trav_begin(T, f3s(0), f3(0, 0, 1), false, -1, 0.0f);
+            bool busy = false;
+            uint32_t ls = 0, kind = 0, rec = 0;   // the ray in hand: local slot, kind, index of its records (g, or g + W.slots)
+            uint32_t idle = 0, progress = 0;
+            while (true) {
+                ER_MARK("tracer_loop_top");
+                // idle lanes take rays from the ring; skipped while fewer than refill_min lanes are idle (it costs the whole wave ~40
+                // instructions and, when rays are taken, a pair of dependent loads) or the ring has nothing published
+                const unsigned long long bm0 = __ballot(busy);
+                if ((64u - (unsigned)__popcll(bm0) >= refill_min || bm0 == 0) && er_ring_load(&s_rq_ctl[ER_RING_COUNT]) > 0) {
+                    uint32_t hb = 0;
+                    const uint32_t granted = st_take(s_rq_ctl, 64u - (uint32_t)__popcll(bm0), hb);
+                    const bool take = !busy && (uint32_t)__popcll(~bm0 & below) < granted;
+                    if (granted > 0) {
+                        uint32_t e = 0;
+                        bool got = false;
+                        if (take) {
+                            got = er_ring_get(s_rq, RQ_LOG2, hb + (uint32_t)__popcll(~bm0 & below), e);
+                            if (!got) atomicOr(status, ST_ERR_RAY);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        if (got) {
+                            ls = e & ST_SLOT_MASK;
+                            kind = e >> ST_SLOT_BITS;
+                            rec = g0 + ls + (kind == 2u ? W.slots : 0u);
+                            const bool shadow = kind != 0u;
+                            const float4 ro = shadow ? W.sh_o(rec) : W.ray_o(rec);
+                            const float4 rd = shadow ? W.sh_d(rec) : W.ray_d(rec);
+                            trav_begin(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), shadow, shadow ? __builtin_bit_cast(int, ro.w) : -1,
+                                       shadow ? rd.w : __builtin_inff());
+                            c_rays++;
+                            busy = true;
+                        }
+                    }
+                }
+                ER_MARK("tracer_refill_end");
+                const unsigned long long bm = __ballot(busy);
+                if (bm == 0) {
+                    if (v_ctl[C_DONE]) break;
+                    __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
+                    const uint32_t pr = er_ring_load(&s_rq_ctl[ER_RING_TAIL]) + er_ring_load(&s_sq_ctl[ER_RING_TAIL]);
+                    if (pr != progress) { progress = pr; idle = 0; }
+                    if (++idle > ST_WATCHDOG) {
+                        if (lane == 0) { atomicOr(status, 1u); s_ctl[C_DONE] = 1; }
+                        break;
+                    }
+                    continue;
+                }
+                idle = 0;
+                ER_MARK("tracer_choose");
+                bool finished = false, do_step = false;
+                TravStep st;
+                st.node = false; st.tri = false; st.two = false; st.tslot = 0; st.noff = 0; st.toff = 0;
+                if (busy) {
+                    if (S.node_count != 0) do_step = trav_choose(T, S, stack, spill, st);
+                    finished = !do_step;
+                }
+                if (COUNT) {
+                    c_wsteps++;
+                    c_busy += (unsigned)__popcll(bm);
+                    c_nl += (unsigned)__popcll(__ballot(st.node));
+                    c_tl += (unsigned)__popcll(__ballot(st.tri));
+                }
+                TravData D;
+                ER_MARK("tracer_fetch");
+                {
+                    const bool top = st.node && st.noff < (uint32_t)(TOP_NODES * ER_NODE8_PIECES);
+                    TravStep sg = st;
+                    if (top) sg.node = false;          // (these lanes' node loads go to the shared dummy address)
+                    trav_fetch(S, sg, D);
+                    if (top) { const float4* q = s_top + st.noff; D.n0 = q[0]; D.n1 = q[1]; D.n2 = q[2]; D.n3 = q[3]; D.n4 = q[4]; }
+                }
+                ER_MARK("tracer_apply");
+                bool occl = false;
+                if (busy) {
+                    if (do_step && trav_apply<COUNT>(T, S, st, D, c_nodes, c_tris)) { occl = true; finished = true; }
+                    if (finished) {
+                        st_write_result(W, rec, T.shadow, occl, T.overflow, T.s0, T.s1);
+                        busy = false;
+                    }
+                }
+                ER_MARK("tracer_publish");
+                // results out, then the slot's in-flight count; the tracer that takes it to zero hands the slot to the shaders
+                if (__ballot(finished)) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    bool last = false;
+                    uint32_t old = 0;
+                    if (finished) {
+                        old = atomicSub(&s_wait[ls], 1u);
+                        last = (old & 0xFFu) == 1u;
+                    }
+                    st_push<ST_SQ_LOG2>(s_sq, s_sq_ctl, last, ls | ((old & ST_FIN) ? (1u << ST_SLOT_BITS) : 0u), status, ST_ERR_SHADE);
+                }
+                ER_MARK("tracer_iter_end");
+            }
+            ER_MARK("tracer_loop_end");
+        }
+    }
+    if (wave >= tracers) {
         // =========================== shader: er_wf_shade's step, fed from the shade ring ===========================
-        int* stack = (int*)(W.spill + (size_t)(blockIdx.x * 16u + wave) * (ER_STACK * 64)) + lane;   // exact re-trace (rare): HBM
+        // exact re-trace (rare): its stack in HBM, behind the contexts' deep-stack areas
+        int* stack = (int*)(W.spill + (size_t)gridDim.x * PL_NCTX * ER_STACK + (size_t)(blockIdx.x * 16u + wave) * (ER_STACK * 64)) + lane;
         bool have = false;
         uint32_t e = 0;
         uint32_t idle = 0, spins = 0, progress = 0;
         while (true) {
-            const int avail = (int)v_ctl[C_SQ_COUNT];
-            if (avail <= 0) {
+            ER_MARK("shader_loop_top");
+            const uint32_t avail = er_ring_load(&s_sq_ctl[ER_RING_COUNT]);
+            if (avail == 0) {
                 if (v_ctl[C_DONE]) break;
                 __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
-                const uint32_t pr = v_ctl[C_RQ_TAIL] + v_ctl[C_SQ_TAIL];
+                const uint32_t pr = er_ring_load(&s_rq_ctl[ER_RING_TAIL]) + er_ring_load(&s_sq_ctl[ER_RING_TAIL]);
                 if (pr != progress) { progress = pr; idle = 0; }
                 if (++idle > ST_WATCHDOG) {
                     if (lane == 0) { atomicOr(status, 2u); s_ctl[C_DONE] = 1; }
@@ -405,32 +726,27 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 continue;
             }
             idle = 0;
-            if (avail < (int)batch_min && spins < 24u) {     // a fuller batch costs the same instructions: wait a little for one
+            if (avail < batch_min && spins < 24u) {     // a fuller batch costs the same instructions: wait a little for one
                 spins++;
                 __builtin_amdgcn_s_sleep(ST_BATCH_SLEEP);
                 continue;
             }
             spins = 0;
+            ER_MARK("shader_take");
             uint32_t hb = 0;
-            const int granted = st_take(&s_ctl[C_SQ_COUNT], &s_ctl[C_SQ_HEAD], 64, hb);
+            const uint32_t granted = st_take(s_sq_ctl, 64u, hb);
             if (granted == 0) continue;          // another wave was quicker
-            have = lane < granted;
-            if (have) {
-                volatile uint32_t* cell = v_sq + ((hb + (uint32_t)lane) & (ST_SQ_CAP - 1u));
-                uint32_t v = 0, guard = 0;
-                while ((v = *cell) == 0 && ++guard < (1u << 22)) __builtin_amdgcn_s_sleep(1);   // (its writer is on its way)
-                *cell = 0;
-                e = v - 1u;
-                if (v == 0) { have = false; atomicOr(status, 8u); }
-            }
+            have = (uint32_t)lane < granted;
+            if (have && !er_ring_get(s_sq, ST_SQ_LOG2, hb + (uint32_t)lane, e)) { have = false; atomicOr(status, ST_ERR_SHADE); }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             bool push_closest = false, push_shadow = false, push_light = false, retire = false;
-            const uint32_t ls = e & 0xFFFFu;
+            const uint32_t ls = e & ST_SLOT_MASK;
             const uint32_t slot = g0 + ls;
             bool want_pixel = false;
             uint32_t rs = 0, left_after = 0, done_idx = 0;
+            ER_MARK("shader_step");
             if (have) {
-                const bool fin_only = (e & ST_SQ_FIN) != 0;
+                const bool fin_only = (e >> ST_SLOT_BITS) != 0;
                 uint32_t idx = W.pix(slot);
                 float4 L4 = W.light(slot), R4 = W.reduc(slot);
                 F3 light = f3(L4.x, L4.y, L4.z), reduction = f3(R4.x, R4.y, R4.z);
@@ -530,26 +846,33 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                     s_wait[ls] = (push_closest ? 1u : 0u) + (push_shadow ? 1u : 0u) + (push_light ? 1u : 0u) + (fin_next ? ST_FIN : 0u);
                 }
             }
+            ER_MARK("shader_pixel_ring");
             // finished samples: pixel back to the tail of the pixel ring (unless that was its last sample), next pixel from the head
             if (__ballot(want_pixel)) {
                 const bool back = want_pixel && left_after > 0;
                 const unsigned long long mb = __ballot(back);
                 if (mb) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the pixel's planes and RNG state first, then its entry
-                    const uint32_t pos = st_reserve(&s_ctl[C_PX_TAIL], back);
-                    if (back) ring[pos & (ring_cap - 1u)] = make_uint2(done_idx, left_after | ST_LAP_TAG(pos, ring_cap));
+                    uint32_t base = 0;
+                    if (lane == 0) base = er_ring_reserve(s_px_ctl, (uint32_t)__popcll(mb));
+                    base = __shfl(base, 0, 64);
+                    if (back) {
+                        const uint32_t pos = base + (uint32_t)__popcll(mb & below), cell = pos & (ring_cap - 1u);
+                        if (!er_bits_acquire(s_pxbits, cell)) atomicOr(status, ST_ERR_PIXEL);      // (waits while the previous lap's entry is unread)
+                        ring[cell] = make_uint2(done_idx, left_after | ST_LAP_TAG(pos, ring_cap));
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0) atomicAdd(&s_ctl[C_PX_COUNT], (uint32_t)__popcll(mb));     // counted only once written
+                    if (lane == 0) er_ring_publish(s_px_ctl, (uint32_t)__popcll(mb));     // counted only once written
                 }
                 // take up to `want` entries (exact count: a slot that has just put its pixel back always finds an entry unless
                 // another slot has taken it)
                 const unsigned long long mw = __ballot(want_pixel);
-                uint32_t hb = 0;
-                const int granted = st_take(&s_ctl[C_PX_COUNT], &s_ctl[C_PX_HEAD], __popcll(mw), hb);
-                const int rank = __popcll(mw & below);
-                if (want_pixel && rank < granted) {
-                    const uint32_t ppos = hb + (uint32_t)rank;
-                    const unsigned long long* cell = (const unsigned long long*)(ring + (ppos & (ring_cap - 1u)));
+                uint32_t hb2 = 0;
+                const uint32_t granted2 = st_take(s_px_ctl, (uint32_t)__popcll(mw), hb2);
+                const uint32_t rank = (uint32_t)__popcll(mw & below);
+                if (want_pixel && rank < granted2) {
+                    const uint32_t ppos = hb2 + rank, pcell = ppos & (ring_cap - 1u);
+                    const unsigned long long* cell = (const unsigned long long*)(ring + pcell);
                     const uint32_t want_tag = ST_LAP_TAG(ppos, ring_cap);
                     // the cell's writer may still be on its way (positions are handed out before they are written): wait for THIS
                     // lap's entry; pixel and count come in one 8-byte load
@@ -559,10 +882,11 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                         w = __hip_atomic_load(cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         y = (uint32_t)(w >> 32);
                         if ((y & ~ST_LEFT_MASK) == want_tag) break;
-                        if (++guard >= (1u << 22)) { y = 0; break; }
+                        if (++guard >= ER_RING_GUARD) { y = 0; break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    er_bits_release(s_pxbits, pcell);      // read: the next lap's writer may have the cell
                     const uint32_t nidx = (uint32_t)w;
                     y &= ST_LEFT_MASK;
                     if (y != 0) {
@@ -570,13 +894,14 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                         s_wait[ls] = 1u;
                         push_closest = true;
                     } else {
-                        atomicOr(status, 4u);    // (cannot happen: a granted entry was never written)
+                        atomicOr(status, ST_ERR_PIXEL);    // (cannot happen: a granted entry was never written)
                         retire = true;
                     }
                 } else if (want_pixel) {
                     retire = true;      // nothing left in the ring: the pixels still unfinished are all in flight in other slots
                 }
             }
+            ER_MARK("shader_publish");
             // the slot's records are written: publish its rays
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             {
@@ -584,26 +909,29 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 const unsigned nc = (unsigned)__popcll(mc), ns = (unsigned)__popcll(ms), nl = (unsigned)__popcll(ml);
                 if (nc + ns + nl) {
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&s_ctl[C_RQ_TAIL], nc + ns + nl);
+                    if (lane == 0) base = er_ring_reserve(s_rq_ctl, nc + ns + nl);
                     base = __shfl(base, 0, 64);
-                    if (push_closest) s_rq[(base + (uint32_t)__popcll(mc & below)) & (ST_RQ_CAP - 1u)] = ls + 1u;
-                    if (push_shadow) s_rq[(base + nc + (uint32_t)__popcll(ms & below)) & (ST_RQ_CAP - 1u)] = (ls | (1u << ST_KIND_SHIFT)) + 1u;
-                    if (EXT && push_light) s_rq[(base + nc + ns + (uint32_t)__popcll(ml & below)) & (ST_RQ_CAP - 1u)] = (ls | (2u << ST_KIND_SHIFT)) + 1u;
-                    if (lane == 0) atomicAdd(&s_ctl[C_RQ_COUNT], nc + ns + nl);      // (after the cells: LDS is in order per wave)
+                    bool ok = true;
+                    if (push_closest) ok = er_ring_put(s_rq, RQ_LOG2, base + (uint32_t)__popcll(mc & below), ls) && ok;
+                    if (push_shadow) ok = er_ring_put(s_rq, RQ_LOG2, base + nc + (uint32_t)__popcll(ms & below), ls | (1u << ST_SLOT_BITS)) && ok;
+                    if (EXT && push_light) ok = er_ring_put(s_rq, RQ_LOG2, base + nc + ns + (uint32_t)__popcll(ml & below), ls | (2u << ST_SLOT_BITS)) && ok;
+                    if (!ok) atomicOr(status, ST_ERR_RAY);
+                    if (lane == 0) er_ring_publish(s_rq_ctl, nc + ns + nl);      // (after the cells: LDS is in order per wave)
                 }
                 const unsigned long long mr = __ballot(retire);
                 if (mr) {
-                    uint32_t oldl = 0;
                     const uint32_t nr = (uint32_t)__popcll(mr);
                     if (lane == 0) {
-                        oldl = atomicSub(&s_ctl[C_LIVE], nr);
+                        const uint32_t oldl = atomicSub(&s_ctl[C_LIVE], nr);
                         if (oldl == nr) s_ctl[C_DONE] = 1;     // the workgroup's last slot has retired
                     }
                 }
             }
             have = false;
         }
+        ER_MARK("shader_loop_end");
     }
+    ER_MARK("epilogue");
     unsigned t0 = st_wave_sum(c_paths), t1 = st_wave_sum(c_bounce), t2 = st_wave_sum(c_rays), t3 = st_wave_sum(c_shaded), t4 = st_wave_sum(c_hdri);
     unsigned t5 = 0, t6 = 0, t7 = 0;
     if (COUNT) { t5 = st_wave_sum(c_nodes); t6 = st_wave_sum(c_tris); t7 = st_wave_sum(c_texels); }
@@ -628,24 +956,37 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
 hipError_t er_probe_stream(const char** which) {
     hipFuncAttributes a;
     *which = "er_stream_kernel";
-    return hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false>);
+    hipError_t e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, false>);
+    if (e != hipSuccess) return e;
+    return hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, true>);
+}
+
+bool er_stream_pool_default() {
+    static const bool v = [] {
+        const char* e = getenv("ER_STREAM_POOL");      // A/B knob: 0 = the first tracer, 1 = the context pool
+        return e ? atoi(e) != 0 : false;
+    }();
+    return v;
 }
 
 void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, void* ring, uint32_t ring_cap, uint32_t* status,
-                      uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream) {
-    static const uint32_t refill_min = [] {
-        const char* e = getenv("ER_STREAM_REFILL_MIN");
-        int v = e ? atoi(e) : 12;
-        return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
-    }();
+                      uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, bool pool, hipStream_t stream) {
+    static const int refill_env = [] { const char* e = getenv("ER_STREAM_REFILL_MIN"); return e ? atoi(e) : -1; }();
     static const uint32_t batch_min = [] {
         const char* e = getenv("ER_STREAM_BATCH_MIN");
         int v = e ? atoi(e) : 48;
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     if (S.owned_tile_count == 0 || n_samples == 0) return;
+    // first tracer: idle lanes of a wave before it refills (12); context pool: entries below which a wave waits a little for a fuller batch
+    int rv = refill_env >= 0 ? refill_env : (pool ? 32 : 12);
+    const uint32_t refill_min = (uint32_t)(rv < 1 ? 1 : (rv > 64 ? 64 : rv));
     const bool ext = er_ext_active(S);
-    auto k = count ? (ext ? er_stream_kernel<true, true> : er_stream_kernel<true, false>) : (ext ? er_stream_kernel<false, true> : er_stream_kernel<false, false>);
+    auto pick = [&](auto p) {
+        constexpr bool P = decltype(p)::value;
+        return count ? (ext ? er_stream_kernel<true, true, P> : er_stream_kernel<true, false, P>) : (ext ? er_stream_kernel<false, true, P> : er_stream_kernel<false, false, P>);
+    };
+    auto k = pool ? pick(std::true_type{}) : pick(std::false_type{});
     StState st;
     st.base = (char*)records;
     st.spill = (uint2*)spill;
@@ -655,3 +996,6 @@ void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lig
 }
 
 uint32_t er_stream_record_bytes(bool lights) { return lights ? ST_STRIDE_LIGHTS : ST_STRIDE_PLAIN; }
+// uint2 entries of the spill buffer: per workgroup, one deep-stack area per context (ER_BVH_MAX_DEPTH entries each; the first tracer
+// uses the same space as 16 waves x 64 lanes) + the exact re-trace stacks of its 16 waves (ER_BVH_MAX_DEPTH x 64 ints each)
+size_t er_stream_spill_entries(uint32_t blocks) { return (size_t)blocks * PL_NCTX * ER_BVH_MAX_DEPTH + (size_t)blocks * 16 * ER_BVH_MAX_DEPTH * 64; }

@@ -144,10 +144,11 @@ ERD void trav_fetch(const DevScene& S, const TravStep& st, TravData& D) {
                  : "memory");
 }
 
-// phase 3.  Returns true when a shadow query found a certain occluder (the ray is then complete).
+// phase 3, TRIANGLE part.  Returns true when a shadow query found a certain occluder (the ray is then complete).
 template <bool COUNT>
-ERD bool trav_apply(Trav& T, const DevScene& S, const TravStep& st, const TravData& D, unsigned& c_nodes, unsigned& c_tris) {
+ERD bool trav_apply_tri(Trav& T, const DevScene& S, const TravStep& st, const TravData& D, unsigned& c_tris) {
     bool occluded = false;
+    ER_MARK("tri_block");
     if (st.tri) {
         const bool two = st.two;
         const uint32_t tslot = st.tslot;
@@ -202,7 +203,14 @@ ERD bool trav_apply(Trav& T, const DevScene& S, const TravStep& st, const TravDa
             occluded = occluded || occl;
         }
     }
-    if (st.node && !occluded) {
+    return occluded;
+}
+
+// phase 3, NODE part: decode one compressed node, test its eight children, set the node group and the triangle group.
+template <bool COUNT>
+ERD void trav_apply_node(Trav& T, const DevScene& S, const TravStep& st, const TravData& D, unsigned& c_nodes) {
+    ER_MARK("node_block");
+    if (st.node) {
         // the pruning bound, after this step's triangles have tightened U
         const float eps_far = (S.scene_scale + (T.U < 3.0e38f ? T.U : 0.0f)) * 4e-6f;
         const float bound = T.U + S.max_lift + eps_far;
@@ -256,6 +264,17 @@ ERD bool trav_apply(Trav& T, const DevScene& S, const TravStep& st, const TravDa
         T.tg_base = __builtin_bit_cast(uint32_t, b4.y);
         T.tg_mask = ((hm >> 8) & present) | (present << 16);
     }
+    ER_MARK("apply_end");
+}
+
+// phase 3 of a lane that may do both parts in one step (wavefront, fused and the first streaming tracer): the triangle part,
+// then -- unless it ended the query -- the node part.
+template <bool COUNT>
+ERD bool trav_apply(Trav& T, const DevScene& S, const TravStep& st, const TravData& D, unsigned& c_nodes, unsigned& c_tris) {
+    const bool occluded = trav_apply_tri<COUNT>(T, S, st, D, c_tris);
+    TravStep sn = st;
+    sn.node = st.node && !occluded;
+    trav_apply_node<COUNT>(T, S, sn, D, c_nodes);
     return occluded;
 }
 

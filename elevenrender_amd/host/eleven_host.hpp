@@ -185,6 +185,8 @@ public:
         d.point_light_count = (uint32_t)pls.size(); d.point_lights = pls.empty() ? nullptr : pls.data();
         d.x_res = scene->x_res; d.y_res = scene->y_res;
         pars.width = scene->x_res; pars.height = scene->y_res;
+        if (er_abi_version() != ER_ABI_VERSION)      // the library fills caller-allocated structs completely: never run against another layout
+            throw std::runtime_error("libeleven_hip.so has ABI version " + std::to_string(er_abi_version()) + ", this host was built for " + std::to_string(ER_ABI_VERSION));
         check(er_scene_create(&d, &er_));
         ErRenderParams p{};
         p.sample_target = pars.sampleTarget; p.block_size = pars.block_size; p.max_bounces = pars.max_bounces;

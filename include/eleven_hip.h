@@ -33,7 +33,9 @@
 extern "C" {
 #endif
 
-#define ER_ABI_VERSION 1
+/* 2: ErCounters grew the four trace_* fields and ErProfile the empty-launch fields (round 2); a host built against the
+ * round-1 header must not pass the version check, since the library fills both caller-allocated structs completely. */
+#define ER_ABI_VERSION 2
 
 typedef enum ErStatus {
     ER_OK = 0,

@@ -1,94 +1,406 @@
-// ring_model.cpp -- host-thread model of the streaming schedule's pixel-ring exchange (csrc/er_stream.hip: st_take, lap-tagged
-// cells, "put the pixel back, then take one"), run under contention on CPU threads.  Each "slot" thread repeatedly finishes a
-// sample of its pixel, puts the pixel back (unless that was its last sample) and takes the next one; a slot that gets none
-// retires.  Checked: every pixel receives exactly n samples, no pixel is ever held by two slots, all slots retire.
-// Built and run by tests/test_stream_protocol_cpu.py with g++ -O2 -pthread (optionally -fsanitize=thread).
-//   ring_model <slots> <pixels> <samples> <variant>      variant 0 = the protocol in use (compare-and-swap take),
-//                                                        variant 1 = subtract-then-restore take (the fault of the first version)
+// ring_model.cpp -- host-thread model of ONE workgroup of the streaming schedule (csrc/er_stream.hip), built on the very ring
+// functions the kernel uses (csrc/er_ring.h compiled with -DER_RING_HOST_MODEL): ray ring, shade ring, the pixel ring with its
+// "entry read" bits and -- in the context-pool variant -- node queue, triangle queue and free list, all with SMALL capacities
+// so that every ring wraps hundreds of times in a run, with the per-slot in-flight counters and the slot / pixel hand-offs
+// in between.  "Waves" are threads of LANES lanes; what a wave does with one reservation (reserve n, put n cells, publish n;
+// grant n, get n cells) is done in that order by its thread.  Slot records, contexts and per-pixel state are PLAIN memory, as on
+// the device: only the protocol orders their accesses, so ThreadSanitizer (tests/test_stream_protocol_cpu.py builds this with
+// -fsanitize=thread) reports any hand-off the protocol does not order.
+//
+// Checked at the end: every pixel received exactly `samples` samples, in order, never held by two slots; every ray was traced
+// exactly once and its result was there when its slot was shaded; every ring ended empty with every cell in the state its lap
+// implies; every context is back in the free list; no guard expired.
+//
+//   ring_model <slots> <pixels> <samples> <variant> [tracers] [shaders] [rq_log2] [nctx_log2]
+//     variant 0  first tracer (a tracer lane owns a ray from the ring to its result)
+//     variant 1  context pool (node queue / triangle queue / free list; rays enter in the idle lanes of a node batch)
+//     variant 2  like 0 but producers do NOT wait for the previous lap's reader (the protocol of round 2: plain overwrite) --
+//                a negative control: with small rings this loses rays or reads the wrong lap, and the model says so
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
-static std::atomic<uint32_t> g_head{0}, g_tail{0};
-static std::atomic<int32_t> g_count{0};
-static std::vector<std::atomic<uint64_t>> g_ring;
-static uint32_t g_cap = 0;
-static std::vector<std::atomic<int>> g_owner;     // pixel -> number of slots holding it (must stay <= 1)
-static std::vector<std::atomic<uint32_t>> g_done; // pixel -> samples finished
-static std::atomic<int> g_errors{0};
+#include "../../elevenrender_amd/csrc/er_ring.h"
 
-static uint32_t lap_tag(uint32_t pos) { return (((pos / g_cap) & 0x7Fu) + 1u) << 24; }
+namespace {
 
-static bool take(int variant, uint32_t& pos) {
-    if (variant == 0) {
-        int32_t seen = g_count.load(std::memory_order_relaxed);
+constexpr int LANES = 4;            // lanes of a model wave
+constexpr uint32_t SLOT_BITS = 10;  // as ST_SLOT_BITS
+constexpr uint32_t FIN = 0x100u;    // as ST_FIN
+
+uint32_t hash32(uint32_t a) { a ^= a >> 16; a *= 0x7feb352dU; a ^= a >> 15; a *= 0x846ca68bU; a ^= a >> 16; return a; }
+
+struct Slot {              // plain memory: one slot record (HBM on the device)
+    uint32_t pixel = 0, left = 0, sample = 0, bounce = 0;
+    uint32_t result[3] = {0, 0, 0};     // written by tracers: 1 + hash(ray identity)
+    uint32_t pushed[3] = {0, 0, 0};     // ray identities the shader pushed for this step (0 = none)
+    bool fin_next = false;
+};
+struct Ctx {               // plain memory: one context (LDS on the device)
+    uint32_t slot = 0, kind = 0, ident = 0, node_steps = 0, tri_steps = 0;
+};
+struct Pixel {
+    uint32_t done = 0;                  // plain: only the holder touches it
+    std::atomic<int> holders{0};
+};
+
+struct Ring {
+    std::vector<uint32_t> cells;
+    uint32_t ctl[ER_RING_WORDS] = {0, 0, 0};
+    uint32_t log2 = 0;
+    void init(uint32_t l2) { log2 = l2; cells.assign(1u << l2, 0u); ctl[0] = ctl[1] = ctl[2] = 0; }
+};
+
+struct Model {
+    uint32_t n_slots, n_pixels, n_samples, variant;
+    std::vector<Slot> slots;
+    std::vector<Ctx> ctx;
+    std::vector<Pixel> pixels;
+    std::vector<uint32_t> s_wait;
+    Ring rq, sq, nq, tq, fl, px;       // px: only ctl is used as a ring; its cells are px_cells + px_bits
+    std::vector<uint64_t> px_cells;
+    std::vector<uint32_t> px_bits;
+    uint32_t px_cap = 0;
+    uint32_t live = 0, done = 0;
+    std::atomic<uint32_t> errors{0}, rays_traced{0}, rays_pushed{0};
+    uint32_t nctx = 0;
+
+    void err(const char* what) {
+        if (errors.fetch_add(1) < 10) fprintf(stderr, "model error: %s\n", what);
+    }
+    static uint32_t lap_tag(uint32_t pos, uint32_t cap) { return ((((pos / cap) & 0x7Fu) + 1u) << 24); }
+    uint32_t path_len(uint32_t pixel, uint32_t sample) const { return 1u + hash32(pixel * 977u + sample * 131u + 7u) % 5u; }
+
+    // wave-level push of up to LANES payloads (one reservation)
+    void push(Ring& r, const uint32_t* payload, int n, bool checked = true) {
+        if (n == 0) return;
+        const uint32_t base = er_ring_reserve(r.ctl, (uint32_t)n);
+        for (int i = 0; i < n; i++) {
+            if (checked) {
+                if (!er_ring_put(r.cells.data(), r.log2, base + (uint32_t)i, payload[i])) err("put guard expired");
+            } else {        // round 2's producer: overwrite whatever is there
+                uint32_t* cell = r.cells.data() + ((base + i) & ((1u << r.log2) - 1u));
+                er_ring_store(cell, er_ring_lap(base + i, r.log2) | ER_RING_FULL | payload[i]);
+            }
+        }
+        er_ring_publish(r.ctl, (uint32_t)n);
+    }
+    int take(Ring& r, uint32_t want, uint32_t* out) {
+        uint32_t base = 0;
+        const uint32_t g = er_ring_grant(r.ctl, want, base);
+        for (uint32_t i = 0; i < g; i++)
+            if (!er_ring_get(r.cells.data(), r.log2, base + i, out[i])) err("get guard expired");
+        return (int)g;
+    }
+
+    void begin_sample(uint32_t s, uint32_t pixel, uint32_t left) {
+        Slot& S = slots[s];
+        if (pixels[pixel].holders.fetch_add(1) != 0) err("a pixel is held by two slots");
+        S.pixel = pixel; S.left = left; S.sample = pixels[pixel].done; S.bounce = 0; S.fin_next = false;
+        S.pushed[0] = 1u + hash32(pixel * 31u + S.sample * 7u);      // the camera ray
+        S.pushed[1] = S.pushed[2] = 0;
+        S.result[0] = S.result[1] = S.result[2] = 0;
+        er_ring_store(&s_wait[s], 1u);
+    }
+
+    // ---- what a tracer does when a ray is complete ----
+    void finish_ray(uint32_t s, uint32_t kind, uint32_t ident, uint32_t* sq_out, int& n_sq) {
+        Slot& S = slots[s];
+        if (S.pushed[kind] != ident) err("a tracer holds a ray its slot did not push");
+        if (S.result[kind] != 0) err("a ray was traced twice");
+        S.result[kind] = 1u + hash32(ident);
+        rays_traced.fetch_add(1);
+        const uint32_t old = er_ring_add(&s_wait[s], (uint32_t)-1);
+        if ((old & 0xFFu) == 0) err("in-flight counter below zero");
+        if ((old & 0xFFu) == 1u) sq_out[n_sq++] = s | ((old & FIN) ? (1u << SLOT_BITS) : 0u);
+    }
+
+    void first_tracer() {
+        uint32_t progress = 0, idle = 0;
         while (true) {
-            if (seen <= 0) return false;
-            if (g_count.compare_exchange_weak(seen, seen - 1, std::memory_order_acq_rel)) break;
-        }
-    } else {
-        const int32_t old = g_count.fetch_sub(1, std::memory_order_acq_rel);
-        if (old <= 0) {
-            std::this_thread::yield();                       // (widens the window of the dip, as a busy GPU does)
-            g_count.fetch_add(1, std::memory_order_acq_rel);
-            return false;
+            uint32_t e[LANES];
+            const int g = take(rq, LANES, e);
+            if (g == 0) {
+                if (er_ring_load(&done)) break;
+                std::this_thread::yield();
+                const uint32_t pr = er_ring_load(&rq.ctl[ER_RING_TAIL]) + er_ring_load(&sq.ctl[ER_RING_TAIL]);
+                if (pr != progress) { progress = pr; idle = 0; }
+                if (++idle > 40000000u) { err("tracer watchdog"); er_ring_store(&done, 1u); break; }
+                continue;
+            }
+            idle = 0;
+            uint32_t out[LANES];
+            int n = 0;
+            for (int i = 0; i < g; i++) {
+                const uint32_t s = e[i] & ((1u << SLOT_BITS) - 1u), kind = e[i] >> SLOT_BITS;
+                if (s >= n_slots || kind > 2) { err("garbage ray-ring entry"); continue; }
+                finish_ray(s, kind, slots[s].pushed[kind], out, n);
+            }
+            push(sq, out, n, variant != 2);
         }
     }
-    pos = g_head.fetch_add(1, std::memory_order_acq_rel);
-    return true;
-}
 
-static void slot_thread(uint32_t pixel, uint32_t left, int variant) {
-    bool have = true;
-    while (have) {
-        if (g_owner[pixel].fetch_add(1) != 0) g_errors++;      // a second holder
-        g_done[pixel].fetch_add(1);                            // "run one sample"
-        g_owner[pixel].fetch_sub(1);
-        left--;
-        if (left > 0) {                                        // put the pixel back: cell first, then the count
-            const uint32_t pos = g_tail.fetch_add(1, std::memory_order_acq_rel);
-            g_ring[pos % g_cap].store(((uint64_t)(left | lap_tag(pos)) << 32) | pixel, std::memory_order_release);
-            g_count.fetch_add(1, std::memory_order_release);
+    void pool_tracer() {
+        uint32_t progress = 0, idle = 0;
+        while (true) {
+            const uint32_t tqc = er_ring_load(&tq.ctl[ER_RING_COUNT]), nqc = er_ring_load(&nq.ctl[ER_RING_COUNT]);
+            const uint32_t rqc = er_ring_load(&rq.ctl[ER_RING_COUNT]), flc = er_ring_load(&fl.ctl[ER_RING_COUNT]);
+            const uint32_t fresh = rqc < flc ? rqc : flc;
+            if (tqc + nqc + fresh == 0) {
+                if (er_ring_load(&done)) break;
+                std::this_thread::yield();
+                const uint32_t pr = er_ring_load(&rq.ctl[ER_RING_TAIL]) + er_ring_load(&sq.ctl[ER_RING_TAIL]) + er_ring_load(&nq.ctl[ER_RING_TAIL]) +
+                                    er_ring_load(&tq.ctl[ER_RING_TAIL]);
+                if (pr != progress) { progress = pr; idle = 0; }
+                if (++idle > 40000000u) { err("tracer watchdog"); er_ring_store(&done, 1u); break; }
+                continue;
+            }
+            idle = 0;
+            uint32_t ids[LANES], to_nq[LANES], to_tq[LANES], to_fl[LANES], to_sq[LANES];
+            int n_nq = 0, n_tq = 0, n_fl = 0, n_sq = 0;
+            auto route = [&](uint32_t id) {
+                Ctx& c = ctx[id];
+                if (c.tri_steps > 0 && (c.node_steps == 0 || (hash32(c.ident + c.node_steps) & 1u))) to_tq[n_tq++] = id;
+                else if (c.node_steps > 0) to_nq[n_nq++] = id;
+                else { finish_ray(c.slot, c.kind, c.ident, to_sq, n_sq); to_fl[n_fl++] = id; }
+            };
+            const bool tri_mode = tqc >= (uint32_t)LANES || (tqc > 0 && tqc >= nqc + fresh);
+            if (tri_mode) {
+                const int g = take(tq, LANES, ids);
+                for (int i = 0; i < g; i++) {
+                    if (ids[i] >= nctx) { err("garbage context id"); continue; }
+                    Ctx& c = ctx[ids[i]];
+                    if (c.tri_steps == 0) err("a context without triangle work in the triangle queue");
+                    else c.tri_steps--;
+                    route(ids[i]);
+                }
+            } else {
+                const int g = take(nq, LANES, ids);
+                for (int i = 0; i < g; i++) {
+                    if (ids[i] >= nctx) { err("garbage context id"); continue; }
+                    Ctx& c = ctx[ids[i]];
+                    if (c.node_steps == 0) err("a context without node work in the node queue");
+                    else c.node_steps--;
+                    route(ids[i]);
+                }
+                if (g < LANES && fresh > 0) {
+                    uint32_t fresh_ids[LANES], rays[LANES];
+                    const uint32_t want = (uint32_t)(LANES - g) < rqc ? (uint32_t)(LANES - g) : rqc;
+                    const int gc = take(fl, want, fresh_ids);
+                    const int gr = gc ? take(rq, (uint32_t)gc, rays) : 0;
+                    uint32_t back[LANES];
+                    int nb = 0;
+                    for (int i = gr; i < gc; i++) back[nb++] = fresh_ids[i];
+                    push(fl, back, nb);
+                    for (int i = 0; i < gr; i++) {
+                        const uint32_t s = rays[i] & ((1u << SLOT_BITS) - 1u), kind = rays[i] >> SLOT_BITS;
+                        if (s >= n_slots || kind > 2 || fresh_ids[i] >= nctx) { err("garbage ray-ring entry"); continue; }
+                        Ctx& c = ctx[fresh_ids[i]];
+                        c.slot = s; c.kind = kind; c.ident = slots[s].pushed[kind];
+                        c.node_steps = 1u + hash32(c.ident) % 6u;
+                        c.tri_steps = hash32(c.ident + 99u) % 4u;
+                        to_nq[n_nq++] = fresh_ids[i];      // (the root step is the next hop)
+                    }
+                }
+            }
+            push(sq, to_sq, n_sq);
+            push(fl, to_fl, n_fl);
+            push(tq, to_tq, n_tq);
+            push(nq, to_nq, n_nq);
         }
-        uint32_t pos = 0;
-        if (!take(variant, pos)) { have = false; break; }      // retire
-        const uint32_t want = lap_tag(pos);
-        uint64_t w;
-        while ((((uint32_t)((w = g_ring[pos % g_cap].load(std::memory_order_acquire)) >> 32)) & 0xFF000000u) != want) std::this_thread::yield();
-        pixel = (uint32_t)w;
-        left = (uint32_t)(w >> 32) & 0x00FFFFFFu;
     }
-}
+
+    void shader() {
+        uint32_t progress = 0, idle = 0;
+        while (true) {
+            uint32_t e[LANES];
+            const int g = take(sq, LANES, e);
+            if (g == 0) {
+                if (er_ring_load(&done)) break;
+                std::this_thread::yield();
+                const uint32_t pr = er_ring_load(&rq.ctl[ER_RING_TAIL]) + er_ring_load(&sq.ctl[ER_RING_TAIL]);
+                if (pr != progress) { progress = pr; idle = 0; }
+                if (++idle > 40000000u) { err("shader watchdog"); er_ring_store(&done, 1u); break; }
+                continue;
+            }
+            idle = 0;
+            uint32_t rays[3 * LANES];
+            int n_rays = 0;
+            uint32_t want_px[LANES], back_px[LANES], back_left[LANES];
+            int n_want = 0, n_back = 0;
+            for (int i = 0; i < g; i++) {
+                const uint32_t s = e[i] & ((1u << SLOT_BITS) - 1u);
+                const bool fin_only = (e[i] >> SLOT_BITS) != 0;
+                if (s >= n_slots) { err("garbage shade-ring entry"); continue; }
+                Slot& S = slots[s];
+                if (fin_only != S.fin_next) err("finalise flag lost");
+                for (int k = 0; k < 3; k++) {        // every pushed ray has its result, and only those
+                    if (S.pushed[k] && S.result[k] != 1u + hash32(S.pushed[k])) err("a slot was shaded before its ray was traced");
+                    if (!S.pushed[k] && S.result[k]) err("a result without a ray");
+                    S.pushed[k] = 0; S.result[k] = 0;
+                }
+                bool donep = fin_only;
+                bool pend_shadow = false, pend_light = false;
+                if (!fin_only) {
+                    S.bounce++;
+                    const uint32_t h = hash32(S.pixel * 13u + S.sample * 5u + S.bounce);
+                    pend_shadow = (h & 1u) != 0;
+                    pend_light = (h & 6u) == 6u;
+                    if (S.bounce >= path_len(S.pixel, S.sample)) donep = true;
+                }
+                if (donep && (pend_shadow || pend_light)) {
+                    S.fin_next = true;
+                } else if (donep) {
+                    Pixel& P = pixels[S.pixel];
+                    if (P.done != S.sample) err("a pixel's samples ran out of order");
+                    P.done++;
+                    P.holders.fetch_sub(1);
+                    S.fin_next = false;
+                    if (S.left - 1 > 0) { back_px[n_back] = S.pixel; back_left[n_back] = S.left - 1; n_back++; }
+                    want_px[n_want++] = s;
+                    continue;
+                }
+                uint32_t n = 0;
+                if (!donep) { S.pushed[0] = 1u + hash32(S.pixel * 31u + S.sample * 7u + S.bounce * 1009u); rays[n_rays++] = s; n++; }
+                if (pend_shadow) { S.pushed[1] = 2u + hash32(S.pixel * 37u + S.sample * 11u + S.bounce * 2003u); rays[n_rays++] = s | (1u << SLOT_BITS); n++; }
+                if (pend_light) { S.pushed[2] = 3u + hash32(S.pixel * 41u + S.sample * 17u + S.bounce * 3001u); rays[n_rays++] = s | (2u << SLOT_BITS); n++; }
+                er_ring_store(&s_wait[s], n + (S.fin_next ? FIN : 0u));
+            }
+            // finished samples: pixels back to the ring (cell behind its "entry read" bit), then as many taken as there are
+            uint32_t retire = 0;
+            if (n_want) {
+                if (n_back) {
+                    const uint32_t base = er_ring_reserve(px.ctl, (uint32_t)n_back);
+                    for (int i = 0; i < n_back; i++) {
+                        const uint32_t pos = base + (uint32_t)i, cell = pos & (px_cap - 1u);
+                        if (variant != 2 && !er_bits_acquire(px_bits.data(), cell)) err("pixel bit guard expired");
+                        __atomic_store_n(&px_cells[cell], ((uint64_t)(back_left[i] | lap_tag(pos, px_cap)) << 32) | back_px[i], __ATOMIC_RELEASE);
+                    }
+                    er_ring_publish(px.ctl, (uint32_t)n_back);
+                }
+                uint32_t base = 0;
+                const uint32_t got = er_ring_grant(px.ctl, (uint32_t)n_want, base);
+                for (int i = 0; i < n_want; i++) {
+                    if ((uint32_t)i >= got) { retire++; continue; }
+                    const uint32_t pos = base + (uint32_t)i, cell = pos & (px_cap - 1u);
+                    uint64_t w;
+                    uint32_t guard = 0;
+                    while ((((uint32_t)((w = __atomic_load_n(&px_cells[cell], __ATOMIC_ACQUIRE)) >> 32)) & 0xFF000000u) != lap_tag(pos, px_cap)) {
+                        if (++guard > 400000000u) { err("pixel cell guard expired"); break; }
+                        std::this_thread::yield();
+                    }
+                    if (variant != 2) er_bits_release(px_bits.data(), cell);
+                    const uint32_t left = (uint32_t)(w >> 32) & 0x00FFFFFFu, pixel = (uint32_t)w;
+                    if (pixel >= n_pixels || left == 0) { err("garbage pixel-ring entry"); retire++; continue; }
+                    begin_sample(want_px[i], pixel, left);
+                    rays[n_rays++] = want_px[i];
+                }
+            }
+            // publish the rays (one reservation per LANES entries, as st_push)
+            rays_pushed.fetch_add((uint32_t)n_rays);
+            for (int o = 0; o < n_rays; o += LANES) push(rq, rays + o, n_rays - o < LANES ? n_rays - o : LANES, variant != 2);
+            if (retire) {
+                const uint32_t old = er_ring_add(&live, (uint32_t)-(int32_t)retire);
+                if (old == retire) er_ring_store(&done, 1u);
+            }
+        }
+    }
+
+    int run(uint32_t tracers, uint32_t shaders, uint32_t rq_log2, uint32_t nctx_log2) {
+        slots.assign(n_slots, Slot());
+        pixels = std::vector<Pixel>(n_pixels);
+        s_wait.assign(n_slots, 0u);
+        uint32_t sq_log2 = 0;
+        while ((1u << sq_log2) < n_slots) sq_log2++;
+        rq.init(rq_log2); sq.init(sq_log2);
+        nctx = 1u << nctx_log2;
+        ctx.assign(nctx, Ctx());
+        nq.init(nctx_log2); tq.init(nctx_log2); fl.init(nctx_log2);
+        for (uint32_t i = 0; i < nctx; i++) fl.cells[i] = ER_RING_FULL | i;
+        fl.ctl[ER_RING_TAIL] = fl.ctl[ER_RING_COUNT] = nctx;
+        px_cap = 1;
+        while (px_cap < n_pixels) px_cap <<= 1;
+        px_cells.assign(px_cap, 0);
+        px_bits.assign((px_cap + 31) / 32, 0u);
+        const uint32_t in_slots = n_slots < n_pixels ? n_slots : n_pixels;
+        for (uint32_t p = in_slots; p < n_pixels; p++) {
+            const uint32_t pos = p - in_slots;
+            px_bits[pos >> 5] |= 1u << (pos & 31u);
+            px_cells[pos] = ((uint64_t)(n_samples | lap_tag(pos, px_cap)) << 32) | p;
+        }
+        px.ctl[ER_RING_TAIL] = px.ctl[ER_RING_COUNT] = n_pixels - in_slots;
+        px.ctl[ER_RING_HEAD] = 0;
+        live = in_slots;
+        done = in_slots == 0 ? 1u : 0u;
+        std::vector<uint32_t> first;
+        for (uint32_t s = 0; s < in_slots; s++) { begin_sample(s, s, n_samples); first.push_back(s); }
+        rays_pushed.fetch_add(in_slots);
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < tracers; t++) th.emplace_back([this] { variant == 1 ? pool_tracer() : first_tracer(); });
+        for (uint32_t t = 0; t < shaders; t++) th.emplace_back([this] { shader(); });
+        // (the camera rays go in while the waves already run: the model's ray ring may be smaller than the slots, the kernel's is
+        // not -- static_assert in er_stream.hip -- and fills it before its waves start)
+        for (size_t o = 0; o < first.size(); o += LANES) push(rq, first.data() + o, (int)(first.size() - o < (size_t)LANES ? first.size() - o : LANES));
+        std::atomic<bool> stop{false};
+        std::thread monitor([&] {       // ER_MODEL_DEBUG=1: the rings' counters once a second (to see where a stuck run is stuck)
+            if (!getenv("ER_MODEL_DEBUG")) return;
+            while (!stop.load()) {
+                std::this_thread::sleep_for(std::chrono::seconds(1));
+                auto d = [&](const char* n, Ring& r) { fprintf(stderr, " %s t%u c%u h%u", n, er_ring_load(&r.ctl[0]), er_ring_load(&r.ctl[1]), er_ring_load(&r.ctl[2])); };
+                d("rq", rq); d("sq", sq); d("nq", nq); d("tq", tq); d("fl", fl); d("px", px);
+                fprintf(stderr, " live %u done %u\n", er_ring_load(&live), er_ring_load(&done));
+            }
+        });
+        for (auto& t : th) t.join();
+        stop.store(true);
+        monitor.join();
+        uint32_t short_px = 0;
+        for (uint32_t p = 0; p < n_pixels; p++) if (pixels[p].done != n_samples) short_px++;
+        auto ring_clean = [&](Ring& r, const char* name, uint32_t expect) {
+            if (r.ctl[ER_RING_COUNT] != expect || r.ctl[ER_RING_TAIL] - r.ctl[ER_RING_HEAD] != expect) { fprintf(stderr, "%s: count %u, tail - head %u, expected %u\n", name, r.ctl[ER_RING_COUNT], r.ctl[ER_RING_TAIL] - r.ctl[ER_RING_HEAD], expect); return 1u; }
+            // every cell in the state its next position implies: the first position >= HEAD that maps to the cell is either
+            // inside [HEAD, TAIL) -- its entry is there, (lap, full) -- or still to be written, (lap, empty)
+            uint32_t bad = 0;
+            const uint32_t cap = 1u << r.log2, head = r.ctl[ER_RING_HEAD];
+            for (uint32_t i = 0; i < cap; i++) {
+                const uint32_t pos = head + ((i - head) & (cap - 1u));
+                const bool inside = (uint32_t)(pos - head) < expect;
+                const uint32_t want = er_ring_lap(pos, r.log2) | (inside ? ER_RING_FULL : 0u);
+                if ((r.cells[i] & ~ER_RING_PAYLOAD_MASK) != want) bad++;
+            }
+            if (bad) fprintf(stderr, "%s: %u cells in an impossible state\n", name, bad);
+            return bad;
+        };
+        uint32_t bad = 0;
+        if (variant != 2) {
+            bad += ring_clean(rq, "ray ring", 0) + ring_clean(sq, "shade ring", 0);
+            if (variant == 1) bad += ring_clean(nq, "node queue", 0) + ring_clean(tq, "triangle queue", 0) + ring_clean(fl, "free list", nctx);
+            for (uint32_t w : px_bits) if (w) bad++;
+        }
+        if (px.ctl[ER_RING_COUNT] != 0) bad++;
+        const uint32_t lost = rays_pushed.load() - rays_traced.load();
+        printf("variant %u slots %u pixels %u samples %u: %u pixels short, %u rays pushed, %u lost, %u protocol errors, %u ring faults, laps: ray ring %u, pixel ring %u\n",
+               variant, in_slots, n_pixels, n_samples, short_px, rays_pushed.load(), lost, errors.load(), bad, rq.ctl[ER_RING_TAIL] >> rq.log2,
+               px.ctl[ER_RING_TAIL] / px_cap);
+        return (short_px || lost || errors.load() || bad) ? 1 : 0;
+    }
+};
+
+}  // namespace
 
 int main(int argc, char** argv) {
-    const uint32_t slots = argc > 1 ? (uint32_t)atoi(argv[1]) : 8, pixels = argc > 2 ? (uint32_t)atoi(argv[2]) : 8;
-    const uint32_t samples = argc > 3 ? (uint32_t)atoi(argv[3]) : 50;
-    const int variant = argc > 4 ? atoi(argv[4]) : 0;
-    // (a ring long enough that no position comes round again within the run: a host thread can be descheduled for
-    // milliseconds between taking a position and reading its cell, which a wave cannot; the lap tags are exercised on the GPU)
-    g_cap = 1u << 15;
-    while (g_cap < pixels * samples + pixels) g_cap <<= 1;
-    g_ring = std::vector<std::atomic<uint64_t>>(g_cap);
-    for (auto& c : g_ring) c.store(0);
-    g_owner = std::vector<std::atomic<int>>(pixels);
-    g_done = std::vector<std::atomic<uint32_t>>(pixels);
-    for (uint32_t p = 0; p < pixels; p++) { g_owner[p].store(0); g_done[p].store(0); }
-    const uint32_t in_slots = slots < pixels ? slots : pixels;
-    for (uint32_t p = in_slots; p < pixels; p++) {             // the pixels that do not start in a slot wait in the ring
-        const uint32_t pos = p - in_slots;
-        g_ring[pos % g_cap].store(((uint64_t)(samples | lap_tag(pos)) << 32) | p);
-    }
-    g_tail.store(pixels - in_slots);
-    g_count.store((int32_t)(pixels - in_slots));
-    std::vector<std::thread> th;
-    for (uint32_t s = 0; s < in_slots; s++) th.emplace_back(slot_thread, s, samples, variant);
-    for (auto& t : th) t.join();
-    uint32_t short_px = 0;
-    for (uint32_t p = 0; p < pixels; p++) if (g_done[p].load() != samples) short_px++;
-    printf("slots %u pixels %u samples %u variant %d: %u pixels short, %d double holders, %d left in the ring\n", in_slots, pixels, samples, variant, short_px,
-           g_errors.load(), (int)g_count.load());
-    return (short_px || g_errors.load() || g_count.load() != 0) ? 1 : 0;
+    Model m;
+    m.n_slots = argc > 1 ? (uint32_t)atoi(argv[1]) : 8;
+    m.n_pixels = argc > 2 ? (uint32_t)atoi(argv[2]) : 8;
+    m.n_samples = argc > 3 ? (uint32_t)atoi(argv[3]) : 50;
+    m.variant = argc > 4 ? (uint32_t)atoi(argv[4]) : 0;
+    const uint32_t tracers = argc > 5 ? (uint32_t)atoi(argv[5]) : 3, shaders = argc > 6 ? (uint32_t)atoi(argv[6]) : 2;
+    const uint32_t rq_log2 = argc > 7 ? (uint32_t)atoi(argv[7]) : 3, nctx_log2 = argc > 8 ? (uint32_t)atoi(argv[8]) : 3;
+    if (m.n_slots > (1u << SLOT_BITS) || m.n_slots == 0 || m.n_pixels == 0) return 2;
+    return m.run(tracers, shaders, rq_log2, nctx_log2);
 }

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert n in abi.SYMBOLS, f"{n} has no ctypes prototype in abi.py"
     for n in declared_symbols("eleven_hip_debug.h"):
         assert hasattr(lib, n)
-    assert lib.er_abi_version() == 1
+    assert lib.er_abi_version() == 2
 
 
 def test_struct_layouts_match_the_header():
