@@ -135,6 +135,7 @@ SYMBOLS = {
     "er_comm_destroy": (None, [_P]),
     "er_gather_pass": (C.c_int, [_P, C.c_int, _P, C.c_uint32]),
     "er_debug_comm_create_local": (C.c_int, [C.c_uint32, C.POINTER(_P)]),
+    "er_comm_create_local": (C.c_int, [C.c_uint32, C.POINTER(_P)]),
     "er_measure_hbm_peak": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, _FP, _FP]),
     "er_debug_eval": (C.c_int, [_P, C.c_int, _FP, C.c_uint32, C.c_uint32, _FP, C.c_uint32]),
     "er_debug_trace_rays": (C.c_int, [_P, _FP, _FP, C.c_uint32, _IP, _FP, _IP, _IP, _FP, _FP, _IP]),

@@ -313,7 +313,6 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         if ((rc = upload(s->d_wf4, nullptr, slots * er_stream_record_bytes(lights_on) / sizeof(float4), s->stream)) != ER_OK) return rc;
         if ((rc = upload(s->d_wf1, nullptr, 2, s->stream)) != ER_OK) return rc;        // [1] status word
         if ((rc = upload(s->d_spill, nullptr, er_stream_spill_entries(s->stream_blocks), s->stream)) != ER_OK) return rc;
-        s->stream_pool = er_stream_pool_default() && wide_nodes < (1u << 24);      // (a context's stack entries keep node indices in 24 bits)
         s->stream_ctl = s->d_wf1.p;
         s->stream_lights = lights_on;
         HIP_TRY(hipMemsetAsync(s->stream_ctl, 0, 2 * sizeof(uint32_t), s->stream));
@@ -478,7 +477,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
         er_launch_fused(s->dev, s->d_ticket.p, s->d_spill.p, n, count, s->fused_blocks, s->stream);
     } else if (s->params.flags & ER_FLAG_STREAM) {
         er_launch_stream(s->dev, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
-                         s->stream_blocks, s->stream_tracers, s->stream_pool, s->stream);
+                         s->stream_blocks, s->stream_tracers, s->stream);
     } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
         er_launch_render(s->dev, n, count, s->stream);
     }

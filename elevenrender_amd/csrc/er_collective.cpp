@@ -2,6 +2,9 @@
 #include "er_collective.h"
 
 #include <dlfcn.h>
+
+#include <chrono>
+#include <condition_variable>
 #include <rccl/rccl.h>   // types and prototypes only: every call goes through the table below (dlopen, no link dependency)
 
 #include "er_scene.h"
@@ -78,14 +81,18 @@ void rccl_destroy(void* self) {
     delete s;
 }
 
-// ---- loopback transport: `world` ranks in one process on one GPU (tests).  A send parks a device copy of the buffer
-// in the shared mailbox; the matching recv (which must come later: the calls of one process are sequential) takes it. ----
+// ---- in-process transport: the `world` ranks of ONE process (one host driving several GPUs from one process -- or several
+// ranks on one GPU, as the tests do).  A send parks a device copy of the buffer (on the sender's device) in the shared
+// mailbox; the matching recv waits for it and copies it into the receiver's buffer with a peer copy (the runtime moves it over
+// xGMI when the devices are peers).  Ranks may call in any order and from different threads. ----
 struct Mailbox {
     std::mutex mtx;
-    std::map<std::pair<uint32_t, uint32_t>, std::pair<void*, size_t>> slots;   // (src, dst) -> device copy
+    std::condition_variable cv;
+    struct Msg { void* copy; size_t bytes; int device; };
+    std::map<std::pair<uint32_t, uint32_t>, Msg> slots;   // (src, dst) -> device copy
     uint64_t bytes_moved = 0, messages = 0;
     ~Mailbox() {
-        for (auto& kv : slots) (void)hipFree(kv.second.first);
+        for (auto& kv : slots) (void)hipFree(kv.second.copy);
     }
 };
 struct LocalSelf {
@@ -96,37 +103,47 @@ int local_nop(void*) { return ER_OK; }
 int local_send(void* self, const void* buf, size_t bytes, uint32_t peer, hipStream_t st) {
     LocalSelf* s = (LocalSelf*)self;
     void* copy = nullptr;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipMalloc(&copy, std::max<size_t>(bytes, 1)));
     hipError_t e = hipMemcpyAsync(copy, buf, bytes, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) { (void)hipFree(copy); return fail(ER_ERR_HIP, std::string("loopback send: ") + hipGetErrorString(e)); }
-    std::lock_guard<std::mutex> lk(s->box->mtx);
-    auto key = std::make_pair(s->rank, peer);
-    auto it = s->box->slots.find(key);
-    if (it != s->box->slots.end()) { (void)hipFree(it->second.first); s->box->slots.erase(it); }
-    s->box->slots[key] = std::make_pair(copy, bytes);
-    s->box->bytes_moved += bytes;
-    s->box->messages++;
+    if (e != hipSuccess) { (void)hipFree(copy); return fail(ER_ERR_HIP, std::string("in-process send: ") + hipGetErrorString(e)); }
+    {
+        std::lock_guard<std::mutex> lk(s->box->mtx);
+        auto key = std::make_pair(s->rank, peer);
+        auto it = s->box->slots.find(key);
+        if (it != s->box->slots.end()) { (void)hipFree(it->second.copy); s->box->slots.erase(it); }      // (an unclaimed older message)
+        s->box->slots[key] = Mailbox::Msg{copy, bytes, dev};
+        s->box->bytes_moved += bytes;
+        s->box->messages++;
+    }
+    s->box->cv.notify_all();
     return ER_OK;
 }
 int local_recv(void* self, void* buf, size_t bytes, uint32_t peer, hipStream_t st) {
     LocalSelf* s = (LocalSelf*)self;
-    std::pair<void*, size_t> msg;
+    Mailbox::Msg msg{};
     {
-        std::lock_guard<std::mutex> lk(s->box->mtx);
-        auto it = s->box->slots.find(std::make_pair(peer, s->rank));
-        if (it == s->box->slots.end()) return fail(ER_ERR_STATE, "loopback recv: rank " + std::to_string(peer) + " has not sent yet (call the non-root ranks first)");
+        std::unique_lock<std::mutex> lk(s->box->mtx);
+        const auto key = std::make_pair(peer, s->rank);
+        static const int wait_s = [] { const char* e = getenv("ER_LOCAL_RECV_TIMEOUT_S"); return e ? std::max(0, atoi(e)) : 120; }();
+        if (!s->box->cv.wait_for(lk, std::chrono::seconds(wait_s), [&] { return s->box->slots.count(key) != 0; }))
+            return fail(ER_ERR_STATE, "in-process recv: rank " + std::to_string(peer) + " has not sent within " + std::to_string(wait_s) + " s (every rank must call er_gather_pass)");
+        auto it = s->box->slots.find(key);
         msg = it->second;
         s->box->slots.erase(it);
     }
     int rc = ER_OK;
-    if (msg.second != bytes) rc = fail(ER_ERR_STATE, "loopback recv: size mismatch (" + std::to_string(msg.second) + " sent, " + std::to_string(bytes) + " expected)");
+    if (msg.bytes != bytes) rc = fail(ER_ERR_STATE, "in-process recv: size mismatch (" + std::to_string(msg.bytes) + " sent, " + std::to_string(bytes) + " expected)");
     if (rc == ER_OK) {
-        hipError_t e = hipMemcpyAsync(buf, msg.first, bytes, hipMemcpyDeviceToDevice, st);
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = dev == msg.device ? hipMemcpyAsync(buf, msg.copy, bytes, hipMemcpyDeviceToDevice, st) : hipMemcpyPeerAsync(buf, dev, msg.copy, msg.device, bytes, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) rc = fail(ER_ERR_HIP, std::string("loopback recv: ") + hipGetErrorString(e));
+        if (e != hipSuccess) rc = fail(ER_ERR_HIP, std::string("in-process recv: ") + hipGetErrorString(e));
     }
-    (void)hipFree(msg.first);
+    (void)hipFree(msg.copy);
     return rc;
 }
 void local_destroy(void* self) { delete (LocalSelf*)self; }
@@ -166,12 +183,12 @@ static int er_comm_create_impl(const uint8_t* id, uint32_t rank, uint32_t world,
     return ER_OK;
 }
 
-static int er_debug_comm_create_local_impl(uint32_t world, ErComm** out) {
-    if (!out || world == 0) return fail(ER_ERR_INVALID_ARG, "er_debug_comm_create_local: bad argument");
+static int er_comm_create_local_impl(uint32_t world, ErComm** out) {
+    if (!out || world == 0) return fail(ER_ERR_INVALID_ARG, "er_comm_create_local: bad argument");
     auto box = std::make_shared<Mailbox>();
     for (uint32_t r = 0; r < world; r++) {
         ErComm* c = new ErComm();
-        c->t = ErTransport{local_nop, local_nop, local_send, local_recv, local_destroy, "loopback"};
+        c->t = ErTransport{local_nop, local_nop, local_send, local_recv, local_destroy, "in-process"};
         c->self = new LocalSelf{box, r};
         c->rank = r; c->world = world; c->device = -1;
         out[r] = c;
@@ -253,7 +270,8 @@ void er_comm_destroy(ErComm* c) {
 int er_gather_pass(ErScene* s, int pass, ErComm* c, uint32_t root) {
     return guarded("er_gather_pass", [&]() -> int { return er_gather_pass_impl(s, pass, c, root); });
 }
-int er_debug_comm_create_local(uint32_t world, ErComm** out) {
-    return guarded("er_debug_comm_create_local", [&]() -> int { return er_debug_comm_create_local_impl(world, out); });
+int er_comm_create_local(uint32_t world, ErComm** out) {
+    return guarded("er_comm_create_local", [&]() -> int { return er_comm_create_local_impl(world, out); });
 }
+int er_debug_comm_create_local(uint32_t world, ErComm** out) { return er_comm_create_local(world, out); }      // (the name the round-2 tests use)
 }  // extern "C"

@@ -7,7 +7,7 @@
 // here is the bounded-queue rule of Vyukov's MPMC ring: every cell carries the LAP of the position it serves and whether it is
 // FULL, producers and consumers both CHECK the cell before they touch it and nobody ever clears anything:
 //
-//     cell = lap(19 bits) | full(1 bit) | payload(12 bits)          all cells start as lap 0, empty
+//     cell = lap(18 bits) | full(1 bit) | payload(13 bits)          all cells start as lap 0, empty
 //     producer of position p:  wait until cell == (lap(p), empty)   -> store (lap(p), full, payload)
 //     consumer of position p:  wait until cell == (lap(p), full, *) -> take payload, store (lap(p) + 1, empty)
 //
@@ -15,8 +15,8 @@
 // cell whose previous entry has been granted but not yet read WAITS for that reader (it is on its way: a granted lane reads
 // its cell unconditionally), and a consumer that is granted a position whose producer has reserved but not yet written it
 // waits for that writer.  No entry can be lost, duplicated or read from the wrong lap, whatever the interleaving; the only
-// number that could alias is the 19-bit lap, i.e. a lane would have to stall between two adjacent instructions while its ring
-// turns 524 288 times.  (Positions are 32-bit and wrap; capacities are powers of two, so `pos & (cap - 1)` and `pos >> log2(cap)`
+// number that could alias is the 18-bit lap, i.e. a lane would have to stall between two adjacent instructions while its ring
+// turns 262 144 times.  (Positions are 32-bit and wrap; capacities are powers of two, so `pos & (cap - 1)` and `pos >> log2(cap)`
 // stay consistent across the wrap.)
 //
 // Counters of a ring (three words): TAIL = positions reserved by producers, COUNT = entries published (written) and not yet
@@ -60,14 +60,16 @@ ER_RING_FN uint32_t er_ring_cas(uint32_t* p, uint32_t expect, uint32_t desired) 
 ER_RING_FN void er_ring_pause() { __builtin_amdgcn_s_sleep(1); }
 #endif
 
-#define ER_RING_PAYLOAD_BITS 12
+#define ER_RING_PAYLOAD_BITS 13
 #define ER_RING_PAYLOAD_MASK ((1u << ER_RING_PAYLOAD_BITS) - 1u)
 #define ER_RING_FULL (1u << ER_RING_PAYLOAD_BITS)
 #define ER_RING_LAP_SHIFT (ER_RING_PAYLOAD_BITS + 1)
 enum { ER_RING_TAIL = 0, ER_RING_COUNT = 1, ER_RING_HEAD = 2, ER_RING_WORDS = 3 };
 // A wait that outlasts this many polls means the protocol itself is broken (a writer or reader that never comes): the
 // caller raises the launch's status word instead of hanging.  Far longer than any wait a correct run can see.
+#ifndef ER_RING_GUARD
 #define ER_RING_GUARD (1u << 22)
+#endif
 
 ER_RING_FN uint32_t er_ring_lap(uint32_t pos, uint32_t cap_log2) { return (pos >> cap_log2) << ER_RING_LAP_SHIFT; }
 

@@ -19,10 +19,9 @@ struct WfState;
 // records: slots * er_stream_record_bytes(lights) bytes (slots = blocks * ER_STREAM_SLOTS; lights: the scene uses the point-light
 // extension, whose queries take a third line per slot); spill: er_stream_spill_entries(blocks) uint2 entries; ring:
 // blocks * ring_cap uint2 entries (the workgroups' pixel rings; ring_cap = a power of two >= 64 * ceil(owned tiles / blocks) and
-// <= ER_STREAM_MAX_RING); status: one word, 0 unless a wave's watchdog or a ring guard fired; pool: the context-pool tracer (er_stream.hip).
+// <= ER_STREAM_MAX_RING); status: one word, 0 unless a wave's watchdog or a ring guard fired.
 void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, void* ring, uint32_t ring_cap, uint32_t* status,
-                      uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, bool pool, hipStream_t stream);
+                      uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream);
 uint32_t er_stream_record_bytes(bool lights);
 size_t er_stream_spill_entries(uint32_t blocks);
-bool er_stream_pool_default();      // which tracer: ER_STREAM_POOL=1 the context pool, 0 the first one (A/B knob)
 hipError_t er_probe_stream(const char** which);

@@ -23,20 +23,13 @@
 //     them with tiny capacities under ThreadSanitizer);
 //   * there is no launch boundary between bounces and therefore no tail in which a few long rays hold a launch open.
 //
-// Two tracers (template parameter POOL):
-//   POOL = false  the first one (round 2): a tracer lane OWNS a ray from the ring to its last step, state in registers,
-//                 er_wf_trace's loop: every iteration issues the node block AND the triangle block for the whole wave,
-//                 although 85 % / 29 % of the busy lanes want them (lane utilisation 0.52, profiles/r02_pmc_valu.csv);
-//   POOL = true   the CONTEXT POOL (round 3): a ray in flight is a 96-byte context in LDS (ray constants, node group,
-//                 triangle group, candidates, a 6-entry stack); tracer waves are stateless executors that take 64 context
-//                 ids from the NODE queue or from the TRIANGLE queue, run only that block for 64 lanes that all want it,
-//                 write the contexts back and route each id to the queue of its next step.  New rays enter in the idle
-//                 lanes of a node batch.  DESIGN.md section 5 has the instruction budget of both.
+// A tracer lane owns a ray from the ring to its last step (state in registers, er_wf_trace's loop).  Three other tracers were
+// built and measured in round 3 -- rays as contexts in LDS served by stateless waves through shared node / triangle queues, by
+// waves with private lists, and two contexts per lane -- all bit-exact, all slower (profiles/r03_experiment_*).
 //
 // Every wave leaves its loop when the workgroup's last slot has retired (s_ctl[C_DONE]); a wave that sees no progress for
 // ~0.2 s, or whose ring wait outlasts ER_RING_GUARD polls, raises the status word and ends the workgroup (it cannot hang).
 #include <cstdlib>
-#include <type_traits>
 #include "er_device.h"
 #include "er_kernels.h"
 #include "er_wavefront.h"
@@ -49,34 +42,30 @@ using namespace erd;
 
 namespace {
 
-#define ST_SLOT_BITS 10          // ring payloads: local slot (10 bits) | kind or flag (2 bits) = ER_RING_PAYLOAD_BITS
-static_assert(ER_STREAM_SLOTS <= (1u << ST_SLOT_BITS), "a local slot must fit the ring payload");
+#define ST_SLOT_BITS 11          // ring payloads: local slot (11 bits) | kind or flag (2 bits) = ER_RING_PAYLOAD_BITS
+static_assert(ER_STREAM_SLOTS <= (1u << ST_SLOT_BITS) && ST_SLOT_BITS + 2 <= ER_RING_PAYLOAD_BITS, "a local slot must fit the ring payload");
 #define ST_SLOT_MASK ((1u << ST_SLOT_BITS) - 1u)
-// ray-ring entry = local slot | kind << 10: 0 closest hit, 1 HDRI shadow query, 2 point-light query;
-// shade-ring entry = local slot | fin << 10 (fin: the slot is only finalised, ER_WF_FINALIZE_ONLY)
+// ray-ring entry = local slot | kind << 11: 0 closest hit, 1 HDRI shadow query, 2 point-light query;
+// shade-ring entry = local slot | fin << 11 (fin: the slot is only finalised, ER_WF_FINALIZE_ONLY)
 #define ST_FIN 0x100u            // the same flag in s_wait
 // ring capacities (log2).  With the checked cells a full ring only makes its producers wait (shader waves for the tracers
 // to drain the ray ring -- which they do whatever the shaders are doing -- never the other way round: the shade ring holds
 // a slot at most once, so ER_STREAM_SLOTS cells can never be full), so capacities are a tuning matter, not a safety margin.
-#define ST_RQ_LOG2_OF(pool) ((pool) ? 11u : 12u)
+#define ST_RQ_LOG2 12u
 #define ST_SQ_LOG2 10u
 static_assert((1u << ST_SQ_LOG2) >= ER_STREAM_SLOTS, "the shade ring must hold every slot once");
 // a wave's reservation (<= 3 x 64 entries) must fit the ring several times over (a reservation longer than the ring would wait for
 // readers of its own unpublished entries), and the camera rays of all slots go in before the waves start
-static_assert((1u << ST_RQ_LOG2_OF(true)) >= ER_STREAM_SLOTS && (1u << ST_RQ_LOG2_OF(true)) >= 4u * 192u, "ray ring too small");
+static_assert((1u << ST_RQ_LOG2) >= ER_STREAM_SLOTS && (1u << ST_RQ_LOG2) >= 4u * 192u, "ray ring too small");
 #ifndef ST_THREADS
 #define ST_THREADS 1024          // 16 waves per CU: four per SIMD, 128 VGPRs each
 #endif
 // north_star: "top BVH levels staged in LDS".  Every workgroup keeps the first wide nodes in LDS (the tree is stored
 // breadth-first: 585 = levels 0-3, 47 KB) and the tracer lanes whose node is one of them read it with ds_read_b128 instead of
 // five global loads: 9 of a ray's 21 node visits on C2.  Measured on C2 with the first tracer: 0 nodes 1240, 73 -> 1274,
-// 256 -> 1286, 585 -> 1330, 800 -> 1331 Msamples/s (profiles/r02_ab_top_levels_in_lds.log).  The context pool needs LDS for
-// its contexts and keeps the first 400.
+// 256 -> 1286, 585 -> 1330, 800 -> 1331 Msamples/s (profiles/r02_ab_top_levels_in_lds.log).
 #ifndef ER_STREAM_TOP_NODES
 #define ER_STREAM_TOP_NODES 585
-#endif
-#ifndef ER_POOL_TOP_NODES
-#define ER_POOL_TOP_NODES 400
 #endif
 #define ST_MAX_TRACERS 12
 enum { C_LIVE = 0, C_DONE, C_INIT, C_WORDS };
@@ -97,22 +86,6 @@ enum { C_LIVE = 0, C_DONE, C_INIT, C_WORDS };
 #define ST_ERR_CTX 32u
 // the pixel ring's "previous entry has been read" bits (er_ring.h): one per cell, so ring_cap <= ER_STREAM_MAX_RING (er_api.cpp checks)
 #define ST_PXBITS_WORDS (ER_STREAM_MAX_RING / 32u)
-
-// ---- the context pool (POOL = true) ----
-#define PL_CTX_LOG2 10u
-#define PL_NCTX (1u << PL_CTX_LOG2)      // contexts (rays in flight) per workgroup; ids fit the ring payload
-#define PL_STACK 6                       // stack entries of a context in LDS (C2: the stack is never deeper; deeper levels: HBM)
-#define PL_PIECES 6                      // 16-byte pieces per context:
-//   [0] idir.xyz, U            [1] noi.xyz, meta        [2] ng_base, ng_bits, tg_base, tg_mask      [3] lo0, lo1, s0, s1
-//   [4..5] the stack: six entries (ng_base | nmask << 24), then their six imask bytes
-// meta = oct7 (bits 0-2) | sp (3-7) | shadow (8) | overflow (9) | kind (10-11) | local slot (12-21)
-#define PL_META_SP_SHIFT 3
-#define PL_META_SP_MASK 31u
-#define PL_META_SHADOW (1u << 8)
-#define PL_META_OVERFLOW (1u << 9)
-#define PL_META_KIND_SHIFT 10
-#define PL_META_SLOT_SHIFT 12
-static_assert(ER_BVH_MAX_DEPTH <= 32, "sp is kept in 5 bits");
 
 __device__ __forceinline__ unsigned st_wave_sum(unsigned v) {
 #pragma unroll
@@ -247,14 +220,13 @@ __device__ __forceinline__ void st_write_result(const StState& W, uint32_t rec, 
 
 }  // namespace
 
-template <bool COUNT, bool EXT, bool POOL>
+template <bool COUNT, bool EXT>
 __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StState W, uint2* ring_base, uint32_t ring_cap, uint32_t* status,
                                                           uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min) {
-    constexpr uint32_t RQ_LOG2 = ST_RQ_LOG2_OF(POOL);
-    constexpr uint32_t TOP_NODES = POOL ? ER_POOL_TOP_NODES : ER_STREAM_TOP_NODES;
+    constexpr uint32_t RQ_LOG2 = ST_RQ_LOG2, SLOTS = ER_STREAM_SLOTS, TOP_NODES = ER_STREAM_TOP_NODES;
     __shared__ uint32_t s_rq[1u << RQ_LOG2];
     __shared__ uint32_t s_sq[1u << ST_SQ_LOG2];
-    __shared__ uint32_t s_wait[ER_STREAM_SLOTS];
+    __shared__ uint32_t s_wait[SLOTS];
     __shared__ uint32_t s_pxbits[ST_PXBITS_WORDS];
     __shared__ uint32_t s_rq_ctl[ER_RING_WORDS], s_sq_ctl[ER_RING_WORDS], s_px_ctl[ER_RING_WORDS], s_ctl[C_WORDS];
     __shared__ float4 s_top[TOP_NODES * ER_NODE8_PIECES];
@@ -262,7 +234,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
         s_top[i] = i < S.node8_count * ER_NODE8_PIECES ? S.nodes8[i] : make_float4(0, 0, 0, 0);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t g0 = blockIdx.x * ER_STREAM_SLOTS;          // this workgroup's first slot
+    const uint32_t g0 = blockIdx.x * SLOTS;          // this workgroup's first slot
     volatile uint32_t* v_ctl = s_ctl;
     const unsigned long long below = (1ull << lane) - 1ull;
 
@@ -273,10 +245,10 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
     if (threadIdx.x < ER_RING_WORDS) { s_rq_ctl[threadIdx.x] = 0; s_sq_ctl[threadIdx.x] = 0; s_px_ctl[threadIdx.x] = 0; }
     if (threadIdx.x < C_WORDS) s_ctl[threadIdx.x] = 0;
     __syncthreads();
-    // this workgroup's pixels in the order of its tiles: the first ER_STREAM_SLOTS valid ones start in the slots, the others
+    // this workgroup's pixels in the order of its tiles: the first SLOTS valid ones start in the slots, the others
     // wait in the pixel ring (entry = pixel, samples left | lap tag; tag 0 marks a cell never written)
     uint2* ring = ring_base + (size_t)blockIdx.x * ring_cap;
-    for (uint32_t s = threadIdx.x; s < ER_STREAM_SLOTS; s += ST_THREADS) s_wait[s] = 0;
+    for (uint32_t s = threadIdx.x; s < SLOTS; s += ST_THREADS) s_wait[s] = 0;
     for (uint32_t k = threadIdx.x; k < ring_cap; k += ST_THREADS) ring[k] = make_uint2(0u, 0u);
     __syncthreads();
     for (uint32_t k0 = 0; k0 < ring_cap; k0 += ST_THREADS) {
@@ -284,13 +256,13 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
         uint32_t px = 0, py = 0;
         const bool valid = n_samples > 0 && k < ring_cap && st_pixel_of(S, blockIdx.x, gridDim.x, k, px, py);
         const uint32_t v = st_reserve(&s_ctl[C_INIT], valid);      // (rank among the valid pixels; order does not matter)
-        const bool to_slot = valid && v < ER_STREAM_SLOTS;
+        const bool to_slot = valid && v < SLOTS;
         const uint32_t idx = py * S.x_res + px;
         if (to_slot) {
             st_begin_sample(S, W, g0 + v, idx, n_samples);
             s_wait[v] = 1u;
         } else if (valid) {
-            const uint32_t pos = v - ER_STREAM_SLOTS;      // (< ring_cap: lap 0 of a ring nobody reads yet)
+            const uint32_t pos = v - SLOTS;      // (< ring_cap: lap 0 of a ring nobody reads yet)
             atomicOr(&s_pxbits[pos >> 5], 1u << (pos & 31u));
             ring[pos] = make_uint2(idx, n_samples | ST_LAP_TAG(pos, ring_cap));
         }
@@ -304,7 +276,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t nv = s_ctl[C_INIT];
-        const uint32_t in_ring = nv > ER_STREAM_SLOTS ? nv - ER_STREAM_SLOTS : 0u;
+        const uint32_t in_ring = nv > SLOTS ? nv - SLOTS : 0u;
         s_px_ctl[ER_RING_HEAD] = 0;
         s_px_ctl[ER_RING_TAIL] = in_ring;
         s_px_ctl[ER_RING_COUNT] = in_ring;
@@ -316,288 +288,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
     unsigned c_paths = 0, c_bounce = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;
     unsigned c_wsteps = 0, c_busy = 0, c_nl = 0, c_tl = 0;
 
-    if constexpr (POOL) {
-        // =========================== tracers of the context pool ===========================
-        __shared__ float4 s_ctx[PL_NCTX * PL_PIECES];
-        __shared__ uint32_t s_nq[PL_NCTX], s_tq[PL_NCTX], s_fl[PL_NCTX];
-        __shared__ uint32_t s_nq_ctl[ER_RING_WORDS], s_tq_ctl[ER_RING_WORDS], s_fl_ctl[ER_RING_WORDS];
-        // node queue and triangle queue empty; every context id in the free list (lap 0, full)
-        for (uint32_t i = threadIdx.x; i < PL_NCTX; i += ST_THREADS) { s_nq[i] = 0; s_tq[i] = 0; s_fl[i] = ER_RING_FULL | i; }
-        if (threadIdx.x < ER_RING_WORDS) {
-            s_nq_ctl[threadIdx.x] = 0; s_tq_ctl[threadIdx.x] = 0;
-            s_fl_ctl[threadIdx.x] = threadIdx.x == ER_RING_HEAD ? 0u : PL_NCTX;      // TAIL = COUNT = PL_NCTX
-        }
-        __syncthreads();
-        // from here on the waves run their own loops: NO workgroup barrier below this line
-        if (wave < tracers) {
-            uint32_t idle = 0, spins = 0, progress = 0;
-            while (true) {
-                ER_MARK("pool_loop_top");
-                // ---- what is there to do?  a full batch of triangle steps, else a full batch of node steps, else whatever is
-                //      there (after a short wait for a fuller batch); new rays ride in the idle lanes of a node batch ----
-                const uint32_t tq = er_ring_load(&s_tq_ctl[ER_RING_COUNT]), nq = er_ring_load(&s_nq_ctl[ER_RING_COUNT]);
-                const uint32_t rq = er_ring_load(&s_rq_ctl[ER_RING_COUNT]), fl = er_ring_load(&s_fl_ctl[ER_RING_COUNT]);
-                const uint32_t fresh = rq < fl ? rq : fl;
-                if (tq + nq + fresh == 0) {
-                    if (v_ctl[C_DONE]) break;
-                    __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
-                    const uint32_t pr = er_ring_load(&s_rq_ctl[ER_RING_TAIL]) + er_ring_load(&s_sq_ctl[ER_RING_TAIL]) + er_ring_load(&s_nq_ctl[ER_RING_TAIL]) +
-                                        er_ring_load(&s_tq_ctl[ER_RING_TAIL]);
-                    if (pr != progress) { progress = pr; idle = 0; }
-                    if (++idle > ST_WATCHDOG) {
-                        if (lane == 0) { atomicOr(status, 1u); s_ctl[C_DONE] = 1; }
-                        break;
-                    }
-                    continue;
-                }
-                idle = 0;
-                const uint32_t best = tq > nq + fresh ? tq : nq + fresh;
-                if (best < refill_min && spins < 8u) {     // a fuller batch costs the same instructions: wait a little for one
-                    spins++;
-                    __builtin_amdgcn_s_sleep(ST_BATCH_SLEEP);
-                    continue;
-                }
-                spins = 0;
-                const bool tri_mode = tq >= 64u || (tq > 0u && tq >= nq + fresh);
-
-                bool have = false, fin = false, to_nq = false, to_tq = false;
-                uint32_t id = 0, meta = 0;
-                int r_s0 = -1, r_s1 = -1;
-                bool r_occluded = false;
-                if (tri_mode) {
-                    // =============== a batch of TRIANGLE steps ===============
-                    ER_MARK("pool_tri_take");
-                    uint32_t hb = 0;
-                    const uint32_t granted = st_take(s_tq_ctl, 64u, hb);
-                    if (granted == 0) continue;          // another wave was quicker
-                    have = (uint32_t)lane < granted;
-                    if (have && !er_ring_get(s_tq, PL_CTX_LOG2, hb + (uint32_t)lane, id)) { atomicOr(status, ST_ERR_CTX); have = false; }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    float4* cx = s_ctx + (size_t)id * PL_PIECES;
-                    Trav T;
-                    TravStep st;
-                    st.node = false; st.tri = false; st.two = false; st.tslot = 0; st.noff = 0; st.toff = 0;
-                    uint32_t ng_bits = 0, tg_base = 0, tg_mask = 0, ls = 0, kind = 0;
-                    if (have) {
-                        const float4 p2 = cx[2];
-                        meta = __builtin_bit_cast(uint32_t, cx[1].w);
-                        ng_bits = __builtin_bit_cast(uint32_t, p2.y);
-                        tg_base = __builtin_bit_cast(uint32_t, p2.z);
-                        tg_mask = __builtin_bit_cast(uint32_t, p2.w);
-                        ls = (meta >> PL_META_SLOT_SHIFT) & ST_SLOT_MASK;
-                        kind = (meta >> PL_META_KIND_SHIFT) & 3u;
-                        // the triangle part of trav_choose: pending bit i is triangle number popcount(present bits below i) of the
-                        // group; a second pending triangle rides along when it is the very next record in memory
-                        const uint32_t m = tg_mask & 0xffffu, present = tg_mask >> 16;
-                        st.tri = m != 0;
-                        const unsigned i = __ffs(m | 0x10000u) - 1;
-                        const uint32_t rest = m & (m - 1u);
-                        const unsigned j = __ffs(rest | 0x10000u) - 1;
-                        st.two = rest != 0 && (present & ((1u << j) - 1u) & ~((2u << i) - 1u)) == 0;
-                        tg_mask = (tg_mask & 0xffff0000u) | (st.two ? (rest & (rest - 1u)) : rest);
-                        st.tslot = tg_base + __popc(present & ((1u << i) - 1u));
-                        st.toff = S.tri_base_pieces + st.tslot * 3u;
-                    }
-                    if (COUNT) { c_wsteps++; c_busy += granted; c_tl += (unsigned)__popcll(__ballot(st.tri)); }
-                    TravData D;
-                    float4 ro, rd;
-                    {
-                        const float4* pt = S.nodes8 + (st.tri ? st.toff : 0u);
-                        const float4* pt2 = (st.tri && st.two) ? pt : S.nodes8;
-                        const float4* pr = have ? W.ray_pair(g0 + ls, kind) : S.nodes8;
-                        ER_MARK("pool_tri_fetch");
-                        asm volatile("global_load_dwordx4 %0, %8, off\n\t"
-                                     "global_load_dwordx4 %1, %8, off offset:16\n\t"
-                                     "global_load_dwordx4 %2, %8, off offset:32\n\t"
-                                     "global_load_dwordx4 %3, %9, off offset:48\n\t"
-                                     "global_load_dwordx4 %4, %9, off offset:64\n\t"
-                                     "global_load_dwordx4 %5, %9, off offset:80\n\t"
-                                     "global_load_dwordx4 %6, %10, off\n\t"
-                                     "global_load_dwordx4 %7, %10, off offset:16\n\t"
-                                     "s_waitcnt vmcnt(0)"
-                                     : "=&v"(D.a), "=&v"(D.b4), "=&v"(D.c), "=&v"(D.dd), "=&v"(D.e4), "=&v"(D.f4), "=&v"(ro), "=&v"(rd)
-                                     : "v"(pt), "v"(pt2), "v"(pr)
-                                     : "memory");
-                    }
-                    ER_MARK("pool_tri_apply");
-                    if (have) {
-                        const bool shadow = (meta & PL_META_SHADOW) != 0;
-                        const float4 p3 = cx[3];
-                        T.o = f3(ro.x, ro.y, ro.z);
-                        T.d = f3(rd.x, rd.y, rd.z);
-                        T.shadow = shadow;
-                        T.skip = shadow ? __builtin_bit_cast(int, ro.w) : -1;
-                        T.limit = shadow ? rd.w : __builtin_inff();
-                        T.U = cx[0].w;
-                        T.lo0 = p3.x; T.lo1 = p3.y;
-                        T.s0 = __builtin_bit_cast(int, p3.z); T.s1 = __builtin_bit_cast(int, p3.w);
-                        T.overflow = (meta & PL_META_OVERFLOW) != 0;
-                        r_occluded = trav_apply_tri<COUNT>(T, S, st, D, c_tris);
-                        cx[0].w = T.U;
-                        cx[3] = make_float4(T.lo0, T.lo1, __builtin_bit_cast(float, T.s0), __builtin_bit_cast(float, T.s1));
-                        cx[2].w = __builtin_bit_cast(float, tg_mask);
-                        if (T.overflow && !(meta & PL_META_OVERFLOW)) {
-                            meta |= PL_META_OVERFLOW;
-                            cx[1].w = __builtin_bit_cast(float, meta);
-                        }
-                        r_s0 = T.s0; r_s1 = T.s1;
-                        const uint32_t sp = (meta >> PL_META_SP_SHIFT) & PL_META_SP_MASK;
-                        to_tq = !r_occluded && (tg_mask & 0xffffu) != 0;
-                        to_nq = !r_occluded && !to_tq && ((ng_bits & 0xffu) != 0 || sp > 0);
-                        fin = !to_tq && !to_nq;
-                    }
-                } else {
-                    // =============== a batch of NODE steps, new rays in its idle lanes ===============
-                    ER_MARK("pool_node_take");
-                    uint32_t hbn = 0, hbf = 0, hbr = 0;
-                    const uint32_t granted = st_take(s_nq_ctl, 64u, hbn);
-                    uint32_t got_ctx = 0, got_ray = 0;
-                    if (granted < 64u && fresh > 0) {
-                        const uint32_t want = (64u - granted) < rq ? (64u - granted) : rq;
-                        got_ctx = st_take(s_fl_ctl, want, hbf);
-                        if (got_ctx) got_ray = st_take(s_rq_ctl, got_ctx, hbr);
-                    }
-                    const uint32_t rnk = (uint32_t)lane - granted;                 // rank among the lanes that took a free context
-                    const bool has_ctx = (uint32_t)lane >= granted && rnk < got_ctx;
-                    bool init = has_ctx && rnk < got_ray;
-                    have = (uint32_t)lane < granted;
-                    uint32_t e = 0;
-                    if (have && !er_ring_get(s_nq, PL_CTX_LOG2, hbn + (uint32_t)lane, id)) { atomicOr(status, ST_ERR_CTX); have = false; }
-                    if (has_ctx && !er_ring_get(s_fl, PL_CTX_LOG2, hbf + rnk, id)) { atomicOr(status, ST_ERR_CTX); init = false; }
-                    if (init && !er_ring_get(s_rq, RQ_LOG2, hbr + rnk, e)) { atomicOr(status, ST_ERR_RAY); init = false; }
-                    // (a context taken for a ray that another wave got first goes straight back)
-                    st_push<PL_CTX_LOG2>(s_fl, s_fl_ctl, has_ctx && !init, id, status, ST_ERR_CTX);
-                    if (granted + got_ray == 0) continue;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    float4* cx = s_ctx + (size_t)id * PL_PIECES;
-                    uint32_t* stk = (uint32_t*)(cx + 4);
-                    volatile uint8_t* stk_im = (volatile uint8_t*)(stk + PL_STACK);
-                    uint2* spill = W.spill + ((size_t)blockIdx.x * PL_NCTX + id) * ER_STACK;
-                    uint32_t sp = 0, oct7 = 0, noff = 0;
-                    bool top = false;
-                    const uint32_t ls_new = e & ST_SLOT_MASK, kind_new = e >> ST_SLOT_BITS;
-                    ER_MARK("pool_node_choose");
-                    if (have) {
-                        const float4 p2 = cx[2];
-                        meta = __builtin_bit_cast(uint32_t, cx[1].w);
-                        uint32_t ng_base = __builtin_bit_cast(uint32_t, p2.x), ng_bits = __builtin_bit_cast(uint32_t, p2.y);
-                        sp = (meta >> PL_META_SP_SHIFT) & PL_META_SP_MASK;
-                        oct7 = meta & 7u;
-                        // the node part of trav_choose: pop when the current group is used up, take its nearest child, push the rest
-                        if ((ng_bits & 0xffu) == 0 && sp > 0) {
-                            sp--;
-                            if (sp < PL_STACK) {
-                                const uint32_t en = *(volatile uint32_t*)(stk + sp);
-                                ng_base = en & 0xffffffu;
-                                ng_bits = (en >> 24) | ((uint32_t)stk_im[sp] << 8);
-                            } else {
-                                const uint2 g = spill[sp - PL_STACK];
-                                ng_base = g.x;
-                                ng_bits = g.y;
-                            }
-                        }
-                        uint32_t nmask = ng_bits & 0xffu;
-                        const uint32_t imask = (ng_bits >> 8) & 0xffu;
-                        const unsigned b = 31 - __clz(nmask | 1u);
-                        nmask &= ~(1u << b);
-                        const unsigned s8 = b ^ oct7;
-                        const uint32_t child = ng_base + __popc(imask & ((1u << s8) - 1u));
-                        if (nmask) {                       // siblings still to visit: one stack entry for the whole group
-                            if (sp < PL_STACK) {
-                                *(volatile uint32_t*)(stk + sp) = ng_base | (nmask << 24);
-                                stk_im[sp] = (uint8_t)imask;
-                            } else {
-                                spill[sp - PL_STACK] = make_uint2(ng_base, nmask | (imask << 8));
-                            }
-                            sp++;
-                        }
-                        noff = child * (uint32_t)ER_NODE8_PIECES;
-                        top = noff < (uint32_t)(TOP_NODES * ER_NODE8_PIECES);
-                    }
-                    if (COUNT) { c_wsteps++; c_busy += granted + got_ray; c_nl += granted; }
-                    TravData D;
-                    {
-                        const float4* pn = have ? (S.nodes8 + (top ? 0u : noff)) : (init ? W.ray_pair(g0 + ls_new, kind_new) : S.nodes8);
-                        ER_MARK("pool_node_fetch");
-                        asm volatile("global_load_dwordx4 %0, %5, off\n\t"
-                                     "global_load_dwordx4 %1, %5, off offset:16\n\t"
-                                     "global_load_dwordx4 %2, %5, off offset:32\n\t"
-                                     "global_load_dwordx4 %3, %5, off offset:48\n\t"
-                                     "global_load_dwordx4 %4, %5, off offset:64\n\t"
-                                     "s_waitcnt vmcnt(0)"
-                                     : "=&v"(D.n0), "=&v"(D.n1), "=&v"(D.n2), "=&v"(D.n3), "=&v"(D.n4)
-                                     : "v"(pn)
-                                     : "memory");
-                        if (top) { const float4* q = s_top + noff; D.n0 = q[0]; D.n1 = q[1]; D.n2 = q[2]; D.n3 = q[3]; D.n4 = q[4]; }
-                    }
-                    ER_MARK("pool_node_apply");
-                    if (have) {
-                        Trav T;
-                        TravStep st;
-                        st.node = true; st.tri = false; st.two = false; st.tslot = 0; st.noff = noff; st.toff = 0;
-                        const float4 p0 = cx[0], p1 = cx[1];
-                        T.idir = f3(p0.x, p0.y, p0.z);
-                        T.U = p0.w;
-                        T.noi = f3(p1.x, p1.y, p1.z);
-                        T.oct7 = oct7;
-                        trav_apply_node<COUNT>(T, S, st, D, c_nodes);
-                        cx[2] = make_float4(__builtin_bit_cast(float, T.ng_base), __builtin_bit_cast(float, T.ng_bits), __builtin_bit_cast(float, T.tg_base),
-                                            __builtin_bit_cast(float, T.tg_mask));
-                        meta = (meta & ~(PL_META_SP_MASK << PL_META_SP_SHIFT)) | (sp << PL_META_SP_SHIFT);
-                        cx[1].w = __builtin_bit_cast(float, meta);
-                        to_tq = (T.tg_mask & 0xffffu) != 0;
-                        to_nq = !to_tq && ((T.ng_bits & 0xffu) != 0 || sp > 0);
-                        fin = !to_tq && !to_nq;
-                        if (fin) {
-                            const float4 p3 = cx[3];
-                            r_s0 = __builtin_bit_cast(int, p3.z);
-                            r_s1 = __builtin_bit_cast(int, p3.w);
-                        }
-                    } else if (init) {
-                        // a new ray: trav_begin, written into the context; its first node step (the root, in LDS) is the next hop
-                        const bool shadow = kind_new != 0u;
-                        Trav T;
-                        trav_begin(T, f3(D.n0.x, D.n0.y, D.n0.z), f3(D.n1.x, D.n1.y, D.n1.z), shadow, shadow ? __builtin_bit_cast(int, D.n0.w) : -1,
-                                   shadow ? D.n1.w : __builtin_inff());
-                        meta = T.oct7 | (shadow ? PL_META_SHADOW : 0u) | (kind_new << PL_META_KIND_SHIFT) | (ls_new << PL_META_SLOT_SHIFT);
-                        cx[0] = make_float4(T.idir.x, T.idir.y, T.idir.z, T.U);
-                        cx[1] = make_float4(T.noi.x, T.noi.y, T.noi.z, __builtin_bit_cast(float, meta));
-                        cx[2] = make_float4(__builtin_bit_cast(float, T.ng_base), __builtin_bit_cast(float, T.ng_bits), __builtin_bit_cast(float, 0u),
-                                            __builtin_bit_cast(float, 0u));
-                        cx[3] = make_float4(0.0f, 0.0f, __builtin_bit_cast(float, -1), __builtin_bit_cast(float, -1));
-                        c_rays++;
-                        have = true;
-                        to_nq = S.node_count != 0;
-                        fin = !to_nq;          // (an empty scene: every query ends at once, nothing hit)
-                    }
-                }
-                // =============== route: finished rays hand their slot on, the others go to the queue of their next step ===============
-                ER_MARK("pool_route");
-                const uint32_t ls = (meta >> PL_META_SLOT_SHIFT) & ST_SLOT_MASK;
-                if (fin) {
-                    const uint32_t kind = (meta >> PL_META_KIND_SHIFT) & 3u;
-                    st_write_result(W, g0 + ls + (kind == 2u ? W.slots : 0u), (meta & PL_META_SHADOW) != 0, r_occluded, (meta & PL_META_OVERFLOW) != 0, r_s0, r_s1);
-                }
-                // the contexts (LDS) and the results (HBM) are written: now publish
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (__ballot(fin)) {
-                    bool last = false;
-                    uint32_t old = 0;
-                    if (fin) {
-                        old = atomicSub(&s_wait[ls], 1u);
-                        last = (old & 0xFFu) == 1u;
-                    }
-                    st_push<ST_SQ_LOG2>(s_sq, s_sq_ctl, last, ls | ((old & ST_FIN) ? (1u << ST_SLOT_BITS) : 0u), status, ST_ERR_SHADE);
-                    st_push<PL_CTX_LOG2>(s_fl, s_fl_ctl, fin, id, status, ST_ERR_CTX);
-                }
-                st_push<PL_CTX_LOG2>(s_tq, s_tq_ctl, to_tq, id, status, ST_ERR_CTX);
-                st_push<PL_CTX_LOG2>(s_nq, s_nq_ctl, to_nq, id, status, ST_ERR_CTX);
-                ER_MARK("pool_iter_end");
-            }
-            ER_MARK("pool_loop_end");
-        }
-    }
-    if constexpr (!POOL) {
+    {
         __shared__ uint2 s_stack[ST_MAX_TRACERS * WF_LDS_STACK * 64];
         __syncthreads();
         // from here on the waves run their own loops: NO workgroup barrier below this line
@@ -671,8 +362,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 }
                 TravData D;
                 ER_MARK("tracer_fetch");
+                const bool top = st.node && st.noff < (uint32_t)(TOP_NODES * ER_NODE8_PIECES);
                 {
-                    const bool top = st.node && st.noff < (uint32_t)(TOP_NODES * ER_NODE8_PIECES);
                     TravStep sg = st;
                     if (top) sg.node = false;          // (these lanes' node loads go to the shared dummy address)
                     trav_fetch(S, sg, D);
@@ -706,8 +397,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
     }
     if (wave >= tracers) {
         // =========================== shader: er_wf_shade's step, fed from the shade ring ===========================
-        // exact re-trace (rare): its stack in HBM, behind the contexts' deep-stack areas
-        int* stack = (int*)(W.spill + (size_t)gridDim.x * PL_NCTX * ER_STACK + (size_t)(blockIdx.x * 16u + wave) * (ER_STACK * 64)) + lane;
+        // exact re-trace (rare): its stack in HBM (the tracer waves use the first `tracers` areas of the workgroup, the shader waves the others)
+        int* stack = (int*)(W.spill + (size_t)(blockIdx.x * 16u + wave) * (ER_STACK * 64)) + lane;
         bool have = false;
         uint32_t e = 0;
         uint32_t idle = 0, spins = 0, progress = 0;
@@ -956,37 +647,24 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
 hipError_t er_probe_stream(const char** which) {
     hipFuncAttributes a;
     *which = "er_stream_kernel";
-    hipError_t e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, false>);
-    if (e != hipSuccess) return e;
-    return hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, true>);
-}
-
-bool er_stream_pool_default() {
-    static const bool v = [] {
-        const char* e = getenv("ER_STREAM_POOL");      // A/B knob: 0 = the first tracer, 1 = the context pool
-        return e ? atoi(e) != 0 : false;
-    }();
-    return v;
+    return hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false>);
 }
 
 void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, void* ring, uint32_t ring_cap, uint32_t* status,
-                      uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, bool pool, hipStream_t stream) {
-    static const int refill_env = [] { const char* e = getenv("ER_STREAM_REFILL_MIN"); return e ? atoi(e) : -1; }();
+                      uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream) {
+    static const uint32_t refill_min = [] {
+        const char* e = getenv("ER_STREAM_REFILL_MIN");
+        int v = e ? atoi(e) : 12;
+        return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+    }();
     static const uint32_t batch_min = [] {
         const char* e = getenv("ER_STREAM_BATCH_MIN");
         int v = e ? atoi(e) : 48;
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     if (S.owned_tile_count == 0 || n_samples == 0) return;
-    // first tracer: idle lanes of a wave before it refills (12); context pool: entries below which a wave waits a little for a fuller batch
-    int rv = refill_env >= 0 ? refill_env : (pool ? 32 : 12);
-    const uint32_t refill_min = (uint32_t)(rv < 1 ? 1 : (rv > 64 ? 64 : rv));
     const bool ext = er_ext_active(S);
-    auto pick = [&](auto p) {
-        constexpr bool P = decltype(p)::value;
-        return count ? (ext ? er_stream_kernel<true, true, P> : er_stream_kernel<true, false, P>) : (ext ? er_stream_kernel<false, true, P> : er_stream_kernel<false, false, P>);
-    };
-    auto k = pool ? pick(std::true_type{}) : pick(std::false_type{});
+    auto k = count ? (ext ? er_stream_kernel<true, true> : er_stream_kernel<true, false>) : (ext ? er_stream_kernel<false, true> : er_stream_kernel<false, false>);
     StState st;
     st.base = (char*)records;
     st.spill = (uint2*)spill;
@@ -996,6 +674,6 @@ void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lig
 }
 
 uint32_t er_stream_record_bytes(bool lights) { return lights ? ST_STRIDE_LIGHTS : ST_STRIDE_PLAIN; }
-// uint2 entries of the spill buffer: per workgroup, one deep-stack area per context (ER_BVH_MAX_DEPTH entries each; the first tracer
-// uses the same space as 16 waves x 64 lanes) + the exact re-trace stacks of its 16 waves (ER_BVH_MAX_DEPTH x 64 ints each)
-size_t er_stream_spill_entries(uint32_t blocks) { return (size_t)blocks * PL_NCTX * ER_BVH_MAX_DEPTH + (size_t)blocks * 16 * ER_BVH_MAX_DEPTH * 64; }
+// uint2 entries of the spill buffer: per workgroup 16 waves x (ER_BVH_MAX_DEPTH x 64): a tracer wave's stack levels beyond the LDS ones,
+// a shader wave's exact re-trace stack (ints, two per entry)
+size_t er_stream_spill_entries(uint32_t blocks) { return (size_t)blocks * 16 * ER_BVH_MAX_DEPTH * 64; }

@@ -22,9 +22,12 @@
 //   * `denoise: true` runs the library's own edge-avoiding filter (er_denoise) instead of OIDN;
 //   * sRGB textures are converted with the real transfer function -- the reference's fast_pow is broken for float
 //     (src/Math.hpp:12-20 zeroes every value above 0.04045), which cannot be intended;
-//   * config accepts the optional keys max_bounces (default 5), point_lights / mis (false) and schedule.
+//   * config accepts the optional keys max_bounces (default 5), point_lights / mis (false), schedule, and gpus / devices /
+//     transport: the frame's pixel tiles are dealt to `gpus` GPUs of this node driven by this one process, and --get_pass
+//     gathers the plane to the first of them (er_gather_pass: RCCL send/recv over xGMI, or in-process peer copies).
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <iomanip>
 #include <map>
@@ -220,6 +223,7 @@ private:
     std::atomic<bool> stop_{false};
     std::mutex err_mtx_;
     std::string render_error_;
+    std::atomic<unsigned> samples_per_call_{0};      // what the render thread's last call was sized to (reported by --get_info)
 
     void dispatch(const CommandLine& cl, std::vector<Message>& extra) {
         if (cl.count("path") || cl.count("sm") || cl.count("output"))
@@ -260,6 +264,10 @@ private:
         if (cl.count("get_info")) {                                          // :282-300
             json::Value j = json::Value::object();
             j["samples"] = rm.get_render_info().samples;
+            // (extra keys, ignored by the plug-in: how the render is spread and how the render thread sizes its calls)
+            j["gpus"] = rm.ranks();
+            if (!rm.transport_used.empty()) j["transport"] = rm.transport_used;
+            j["samples_per_call"] = samples_per_call_.load();
             im->write_message(Message::json_data(j));
             return;
         }
@@ -308,6 +316,18 @@ private:
             else if (s == "megakernel") rp.flags |= ER_FLAG_MEGAKERNEL;
             else if (s != "auto") throw std::runtime_error("config schedule '" + s + "' not recognised");
         }
+        // several GPUs of this node behind the one session (SURVEY.md section 5 planned `gpus` beside max_bounces; reference hook
+        // src/CommandManager.cpp:154-172): "gpus": N, optionally "devices": [ordinals] and "transport": "auto" | "rccl" | "local"
+        if (const json::Value* v = j.if_contains("gpus")) {
+            const long long g = v->as_int64();
+            if (g < 1 || g > 64) throw std::runtime_error("config gpus out of range (1 .. 64)");
+            rp.gpus = (unsigned)g;
+        }
+        if (const json::Value* v = j.if_contains("devices")) {
+            for (const json::Value& o : v->as_array()) rp.devices.push_back((int)o.as_int64());
+            if (rp.devices.size() != rp.gpus) throw std::runtime_error("config devices must list one ordinal per gpu");
+        }
+        if (const json::Value* v = j.if_contains("transport")) rp.transport = v->as_string();
         stop_render_thread();
         rm.pars = rp;
         scene.x_res = rp.width;
@@ -322,11 +342,19 @@ private:
         const unsigned target = rm.pars.sampleTarget;
         t_rend_ = std::thread([this, target] {          // kernel_render_enqueue, src/kernel.cpp:680-706: `target` samples
             try {
-                unsigned done = 0;
+                // One sample first (the plug-in's preview wants a first pass soon), then calls sized by TIME: a call of the
+                // streaming schedule costs about a millisecond of start-up and tail whatever its length, so each call is given
+                // about 50 ms of work -- long enough to lose ~2 % to that, short enough that --get_pass (a sample-boundary
+                // snapshot, ordered behind the call in flight) and a restart answer within a frame or two of the viewer.
+                unsigned done = 0, n = 1;
                 while (done < target && !stop_) {
-                    const unsigned n = std::min(4u, target - done);   // a few samples per call keeps get_pass responsive
+                    n = std::min(n, target - done);
+                    const auto t0 = std::chrono::steady_clock::now();
                     rm.render(n);
+                    const double per_sample = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / n;
                     done += n;
+                    samples_per_call_ = n;
+                    n = (unsigned)std::min(256.0, std::max(1.0, std::ceil(0.050 / std::max(per_sample, 1e-6))));
                 }
             } catch (const std::exception& e) {
                 std::lock_guard<std::mutex> lk(err_mtx_);

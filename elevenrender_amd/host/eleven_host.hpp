@@ -14,6 +14,7 @@
 // Only what the per-sample path consumes is mirrored (OBJ ingest: eleven_obj.hpp beside this file; denoise(): the
 // library's own filter in place of DenoiseManager's OIDN call); commands and TCP stay the reference's.  Errors surface as std::runtime_error carrying er_last_error(); nothing falls back to the CPU.
 #pragma once
+#include <thread>
 #include <algorithm>
 #include <cctype>
 #include <stdexcept>
@@ -118,6 +119,13 @@ struct RenderParameters {   // src/kernel.h:51-69
     std::string device;     // "name|platform" (src/Managers.cpp:201); empty = device 0
     bool denoise = false;
     unsigned max_bounces = 5, rank = 0, world = 1, flags = 0;
+    // Several GPUs of this node driven by this one process (north_star: pixel tiles shard over the GPUs of a node, one combine
+    // per read-back): `gpus` ranks, rank r on devices[r] (default: ordinals 0 .. gpus-1 after `device`; an ordinal may repeat --
+    // several ranks on one GPU, which is how a one-GPU box tests this path).  transport: "rccl" (ncclSend/ncclRecv over xGMI),
+    // "local" (in-process peer copies) or "auto" = rccl when every rank has its own device and RCCL loads, else local.
+    unsigned gpus = 1;
+    std::vector<int> devices;
+    std::string transport = "auto";
 };
 
 inline int parsePass(std::string s) {   // src/kernel.cpp:50-73: unknown names -> BEAUTY
@@ -133,11 +141,12 @@ class RenderingManager {
 public:
     struct RenderInfo { unsigned samples = 0; };
     RenderParameters pars;
+    std::string transport_used;      // "" (one GPU), "rccl" or "in-process"
 
-    ~RenderingManager() { if (er_) er_scene_destroy(er_); }
+    ~RenderingManager() { release(); }
 
     void start_rendering(Scene* scene) {   // src/Managers.cpp:234-275 (without spawning the render thread)
-        if (er_) { er_scene_destroy(er_); er_ = nullptr; }
+        release();
         size_t n = scene->tris.size();
         std::vector<float> v(n * 9), nn(n * 9), tt(n * 9), uv(n * 6), sign(n);
         std::vector<int32_t> mat(n);
@@ -187,32 +196,127 @@ public:
         pars.width = scene->x_res; pars.height = scene->y_res;
         if (er_abi_version() != ER_ABI_VERSION)      // the library fills caller-allocated structs completely: never run against another layout
             throw std::runtime_error("libeleven_hip.so has ABI version " + std::to_string(er_abi_version()) + ", this host was built for " + std::to_string(ER_ABI_VERSION));
-        check(er_scene_create(&d, &er_));
-        ErRenderParams p{};
-        p.sample_target = pars.sampleTarget; p.block_size = pars.block_size; p.max_bounces = pars.max_bounces;
-        p.rank = pars.rank; p.world = pars.world; p.flags = pars.flags;
-        p.device = 0;
-        if (!pars.device.empty()) { int dev = er_device_find(pars.device.c_str()); check(dev < 0 ? dev : ER_OK); p.device = dev; }
-        check(er_render_begin(er_, &p));
+
+        // ---- which ranks on which devices ----
+        const bool multi = pars.gpus > 1;
+        const unsigned world = multi ? pars.gpus : pars.world;
+        if (world == 0 || world > 64) throw std::runtime_error("config gpus out of range (1 .. 64)");
+        int first = 0;
+        if (!pars.device.empty()) { first = er_device_find(pars.device.c_str()); check(first < 0 ? first : ER_OK); }
+        std::vector<int> devs;
+        if (multi) {
+            devs = pars.devices;
+            if (devs.empty()) {
+                const int have = er_device_count();
+                if (have <= 0) check(ER_ERR_NO_DEVICE, "no gfx950 device is visible");
+                if ((int)world > have)
+                    throw std::runtime_error("config asks for " + std::to_string(world) + " gpus, " + std::to_string(have) + " visible (name the ordinals in \"devices\" to put several ranks on one GPU)");
+                for (unsigned r = 0; r < world; r++) devs.push_back((first + (int)r) % have);
+            }
+            if (devs.size() != world) throw std::runtime_error("config devices must list one ordinal per gpu");
+        }
+        // ---- one scene per rank (the scene is replicated, the pixel tiles are dealt (tx + ty) % world); begun side by side ----
+        const unsigned ranks = multi ? world : 1;
+        ers_.assign(ranks, nullptr);
+        std::vector<std::string> errs(ranks);
+        std::vector<std::thread> th;
+        for (unsigned r = 0; r < ranks; r++)
+            th.emplace_back([&, r] {
+                ErRenderParams p{};
+                p.sample_target = pars.sampleTarget; p.block_size = pars.block_size; p.max_bounces = pars.max_bounces;
+                p.rank = multi ? r : pars.rank; p.world = world; p.flags = pars.flags;
+                p.device = multi ? devs[r] : first;
+                int rc = er_scene_create(&d, &ers_[r]);
+                if (rc == ER_OK) rc = er_render_begin(ers_[r], &p);
+                if (rc != ER_OK) errs[r] = er_last_error();
+            });
+        for (auto& t : th) t.join();
+        for (unsigned r = 0; r < ranks; r++) if (!errs[r].empty()) { std::string e = errs[r]; release(); throw std::runtime_error(e); }
+        // ---- the combine's communicators ----
+        if (multi) {
+            bool distinct = true;
+            for (unsigned a = 0; a < world; a++) for (unsigned b = a + 1; b < world; b++) if (devs[a] == devs[b]) distinct = false;
+            std::string tr = pars.transport;
+            if (tr != "auto" && tr != "rccl" && tr != "local") throw std::runtime_error("config transport '" + tr + "' not recognised");
+            comms_.assign(world, nullptr);
+            if (tr == "rccl" && !distinct) { release(); throw std::runtime_error("transport rccl needs one device per rank"); }
+            if (tr != "local" && distinct) {
+                uint8_t id[ER_COMM_ID_BYTES];
+                int rc = er_comm_unique_id(id);
+                if (rc == ER_OK) {
+                    std::vector<int> rcs(world, ER_OK);
+                    std::vector<std::thread> ct;        // ncclCommInitRank blocks until every rank has joined: one thread per rank
+                    for (unsigned r = 0; r < world; r++) ct.emplace_back([&, r] { rcs[r] = er_comm_create(id, r, world, devs[r], &comms_[r]); if (rcs[r] != ER_OK) errs[r] = er_last_error(); });
+                    for (auto& t : ct) t.join();
+                    for (unsigned r = 0; r < world; r++) if (rcs[r] != ER_OK) rc = rcs[r];
+                }
+                if (rc == ER_OK) transport_used = "rccl";
+                else if (tr == "rccl") { std::string e = er_last_error(); for (auto& x : errs) if (!x.empty()) e = x; release(); throw std::runtime_error(e); }
+                else for (auto*& cm : comms_) { if (cm) er_comm_destroy(cm); cm = nullptr; }
+            }
+            if (transport_used.empty()) {
+                check(er_comm_create_local(world, comms_.data()));
+                transport_used = "in-process";
+            }
+        }
     }
-    void render(unsigned n_samples) { check(er_render_samples(er_, n_samples)); }   // body of kernel_render_enqueue's loop
+    // body of kernel_render_enqueue's loop: n more samples on every rank (the launches go out side by side, then the waits)
+    void render(unsigned n_samples) {
+        std::string err;
+        for (ErScene* e : ers_) if (er_render_samples_async(e, n_samples) != ER_OK && err.empty()) err = er_last_error();
+        for (ErScene* e : ers_) if (er_wait(e, nullptr) != ER_OK && err.empty()) err = er_last_error();
+        if (!err.empty()) throw std::runtime_error(err);
+    }
     std::vector<float> get_pass(const std::string& pass) {   // src/Managers.cpp:287-302
         std::vector<float> out((size_t)pars.width * pars.height * 4);
-        if (!er_) throw std::runtime_error("get_pass: no render has been started");
-        check(er_read_pass(er_, parsePass(pass), out.data()));
+        if (ers_.empty()) throw std::runtime_error("get_pass: no render has been started");
+        gather(parsePass(pass));
+        check(er_read_pass(ers_[0], parsePass(pass), out.data()));
         return out;
     }
-    // DenoiseManager::denoise (src/Managers.cpp:319-343) called OIDN on the host; here the device fills the DENOISE plane
-    void denoise(unsigned levels = 0, float colour_sigma = 0) { check(er_denoise(er_, levels, colour_sigma)); }
-    RenderInfo get_render_info() {   // src/Managers.cpp:211-232
+    // DenoiseManager::denoise (src/Managers.cpp:319-343) called OIDN on the host; here the device fills the DENOISE plane --
+    // on a sharded frame on rank 0, after BEAUTY and NORMAL have been gathered there
+    void denoise(unsigned levels = 0, float colour_sigma = 0) {
+        if (ers_.empty()) throw std::runtime_error("denoise: no render has been started");
+        gather(ER_PASS_BEAUTY);
+        gather(ER_PASS_NORMAL);
+        check(er_denoise(ers_[0], levels, colour_sigma));
+    }
+    RenderInfo get_render_info() {   // src/Managers.cpp:211-232; several ranks: the one that is furthest behind
         RenderInfo i;
-        check(er_samples_done(er_, &i.samples));
+        if (ers_.empty()) throw std::runtime_error("get_info: no render has been started");
+        i.samples = ~0u;
+        for (ErScene* e : ers_) {
+            unsigned s = 0;
+            check(er_samples_done(e, &s));
+            i.samples = std::min(i.samples, s);
+        }
         return i;
     }
+    unsigned ranks() const { return (unsigned)ers_.size(); }
 
 private:
-    ErScene* er_ = nullptr;
-    static void check(int rc) { if (rc != ER_OK) throw std::runtime_error(er_last_error()); }
+    std::vector<ErScene*> ers_;
+    std::vector<ErComm*> comms_;
+    static void check(int rc, const char* what = nullptr) { if (rc != ER_OK) throw std::runtime_error(what ? what : er_last_error()); }
+    // every rank's owned pixels of one plane -> rank 0's plane: one er_gather_pass per rank, side by side (the RCCL sends block until
+    // the root has posted its receives, so the ranks cannot take turns on one thread)
+    void gather(int pass) {
+        if (ers_.size() < 2 || pass == ER_PASS_DENOISE) return;      // (the DENOISE plane is only ever written on rank 0)
+        std::vector<std::string> errs(ers_.size());
+        std::vector<std::thread> th;
+        for (size_t r = 0; r < ers_.size(); r++)
+            th.emplace_back([&, r] { if (er_gather_pass(ers_[r], pass, comms_[r], 0) != ER_OK) errs[r] = er_last_error(); });
+        for (auto& t : th) t.join();
+        for (auto& e : errs) if (!e.empty()) throw std::runtime_error(e);
+    }
+    void release() {
+        for (ErComm* c : comms_) if (c) er_comm_destroy(c);
+        comms_.clear();
+        for (ErScene* e : ers_) if (e) er_scene_destroy(e);
+        ers_.clear();
+        transport_used.clear();
+    }
 };
 
 }  // namespace eleven

@@ -240,6 +240,11 @@ typedef struct ErComm ErComm;
 #define ER_COMM_ID_BYTES 128
 int er_comm_unique_id(uint8_t id[ER_COMM_ID_BYTES]);
 int er_comm_create(const uint8_t id[ER_COMM_ID_BYTES], uint32_t rank, uint32_t world, int device, ErComm** out);
+/* The same for the ranks of ONE process (a host that drives several GPUs itself, reference hook: RenderingManager with N
+ * devices; also several ranks on one GPU): `world` communicators over an in-process transport -- a send parks a device copy,
+ * the matching receive copies it device to device (peer copy over xGMI between two GPUs); no RCCL involved.  out[world].
+ * er_gather_pass may be called by the ranks in any order, from one thread per rank or (non-roots first) from one thread. */
+int er_comm_create_local(uint32_t world, ErComm** out);
 void er_comm_destroy(ErComm* comm);
 int er_gather_pass(ErScene* scene, int pass, ErComm* comm, uint32_t root);
 

@@ -1,20 +1,18 @@
 // ring_model.cpp -- host-thread model of ONE workgroup of the streaming schedule (csrc/er_stream.hip), built on the very ring
-// functions the kernel uses (csrc/er_ring.h compiled with -DER_RING_HOST_MODEL): ray ring, shade ring, the pixel ring with its
-// "entry read" bits and -- in the context-pool variant -- node queue, triangle queue and free list, all with SMALL capacities
-// so that every ring wraps hundreds of times in a run, with the per-slot in-flight counters and the slot / pixel hand-offs
+// functions the kernel uses (csrc/er_ring.h compiled with -DER_RING_HOST_MODEL): ray ring, shade ring and the pixel ring with its
+// "entry read" bits, all with SMALL capacities so that every ring wraps hundreds of times in a run, with the per-slot in-flight counters and the slot / pixel hand-offs
 // in between.  "Waves" are threads of LANES lanes; what a wave does with one reservation (reserve n, put n cells, publish n;
-// grant n, get n cells) is done in that order by its thread.  Slot records, contexts and per-pixel state are PLAIN memory, as on
+// grant n, get n cells) is done in that order by its thread.  Slot records and per-pixel state are PLAIN memory, as on
 // the device: only the protocol orders their accesses, so ThreadSanitizer (tests/test_stream_protocol_cpu.py builds this with
 // -fsanitize=thread) reports any hand-off the protocol does not order.
 //
 // Checked at the end: every pixel received exactly `samples` samples, in order, never held by two slots; every ray was traced
 // exactly once and its result was there when its slot was shaded; every ring ended empty with every cell in the state its lap
-// implies; every context is back in the free list; no guard expired.
+// implies; no guard expired.
 //
-//   ring_model <slots> <pixels> <samples> <variant> [tracers] [shaders] [rq_log2] [nctx_log2]
-//     variant 0  first tracer (a tracer lane owns a ray from the ring to its result)
-//     variant 1  context pool (node queue / triangle queue / free list; rays enter in the idle lanes of a node batch)
-//     variant 2  like 0 but producers do NOT wait for the previous lap's reader (the protocol of round 2: plain overwrite) --
+//   ring_model <slots> <pixels> <samples> <variant> [tracers] [shaders] [rq_log2]
+//     variant 0  the protocol of the kernel
+//     variant 2  the same, but producers do NOT wait for the previous lap's reader (the protocol of round 2: plain overwrite) --
 //                a negative control: with small rings this loses rays or reads the wrong lap, and the model says so
 #include <atomic>
 #include <chrono>
@@ -41,9 +39,6 @@ struct Slot {              // plain memory: one slot record (HBM on the device)
     uint32_t pushed[3] = {0, 0, 0};     // ray identities the shader pushed for this step (0 = none)
     bool fin_next = false;
 };
-struct Ctx {               // plain memory: one context (LDS on the device)
-    uint32_t slot = 0, kind = 0, ident = 0, node_steps = 0, tri_steps = 0;
-};
 struct Pixel {
     uint32_t done = 0;                  // plain: only the holder touches it
     std::atomic<int> holders{0};
@@ -59,16 +54,14 @@ struct Ring {
 struct Model {
     uint32_t n_slots, n_pixels, n_samples, variant;
     std::vector<Slot> slots;
-    std::vector<Ctx> ctx;
     std::vector<Pixel> pixels;
     std::vector<uint32_t> s_wait;
-    Ring rq, sq, nq, tq, fl, px;       // px: only ctl is used as a ring; its cells are px_cells + px_bits
+    Ring rq, sq, px;       // px: only ctl is used as a ring; its cells are px_cells + px_bits
     std::vector<uint64_t> px_cells;
     std::vector<uint32_t> px_bits;
     uint32_t px_cap = 0;
     uint32_t live = 0, done = 0;
     std::atomic<uint32_t> errors{0}, rays_traced{0}, rays_pushed{0};
-    uint32_t nctx = 0;
 
     void err(const char* what) {
         if (errors.fetch_add(1) < 10) fprintf(stderr, "model error: %s\n", what);
@@ -142,76 +135,6 @@ struct Model {
                 finish_ray(s, kind, slots[s].pushed[kind], out, n);
             }
             push(sq, out, n, variant != 2);
-        }
-    }
-
-    void pool_tracer() {
-        uint32_t progress = 0, idle = 0;
-        while (true) {
-            const uint32_t tqc = er_ring_load(&tq.ctl[ER_RING_COUNT]), nqc = er_ring_load(&nq.ctl[ER_RING_COUNT]);
-            const uint32_t rqc = er_ring_load(&rq.ctl[ER_RING_COUNT]), flc = er_ring_load(&fl.ctl[ER_RING_COUNT]);
-            const uint32_t fresh = rqc < flc ? rqc : flc;
-            if (tqc + nqc + fresh == 0) {
-                if (er_ring_load(&done)) break;
-                std::this_thread::yield();
-                const uint32_t pr = er_ring_load(&rq.ctl[ER_RING_TAIL]) + er_ring_load(&sq.ctl[ER_RING_TAIL]) + er_ring_load(&nq.ctl[ER_RING_TAIL]) +
-                                    er_ring_load(&tq.ctl[ER_RING_TAIL]);
-                if (pr != progress) { progress = pr; idle = 0; }
-                if (++idle > 40000000u) { err("tracer watchdog"); er_ring_store(&done, 1u); break; }
-                continue;
-            }
-            idle = 0;
-            uint32_t ids[LANES], to_nq[LANES], to_tq[LANES], to_fl[LANES], to_sq[LANES];
-            int n_nq = 0, n_tq = 0, n_fl = 0, n_sq = 0;
-            auto route = [&](uint32_t id) {
-                Ctx& c = ctx[id];
-                if (c.tri_steps > 0 && (c.node_steps == 0 || (hash32(c.ident + c.node_steps) & 1u))) to_tq[n_tq++] = id;
-                else if (c.node_steps > 0) to_nq[n_nq++] = id;
-                else { finish_ray(c.slot, c.kind, c.ident, to_sq, n_sq); to_fl[n_fl++] = id; }
-            };
-            const bool tri_mode = tqc >= (uint32_t)LANES || (tqc > 0 && tqc >= nqc + fresh);
-            if (tri_mode) {
-                const int g = take(tq, LANES, ids);
-                for (int i = 0; i < g; i++) {
-                    if (ids[i] >= nctx) { err("garbage context id"); continue; }
-                    Ctx& c = ctx[ids[i]];
-                    if (c.tri_steps == 0) err("a context without triangle work in the triangle queue");
-                    else c.tri_steps--;
-                    route(ids[i]);
-                }
-            } else {
-                const int g = take(nq, LANES, ids);
-                for (int i = 0; i < g; i++) {
-                    if (ids[i] >= nctx) { err("garbage context id"); continue; }
-                    Ctx& c = ctx[ids[i]];
-                    if (c.node_steps == 0) err("a context without node work in the node queue");
-                    else c.node_steps--;
-                    route(ids[i]);
-                }
-                if (g < LANES && fresh > 0) {
-                    uint32_t fresh_ids[LANES], rays[LANES];
-                    const uint32_t want = (uint32_t)(LANES - g) < rqc ? (uint32_t)(LANES - g) : rqc;
-                    const int gc = take(fl, want, fresh_ids);
-                    const int gr = gc ? take(rq, (uint32_t)gc, rays) : 0;
-                    uint32_t back[LANES];
-                    int nb = 0;
-                    for (int i = gr; i < gc; i++) back[nb++] = fresh_ids[i];
-                    push(fl, back, nb);
-                    for (int i = 0; i < gr; i++) {
-                        const uint32_t s = rays[i] & ((1u << SLOT_BITS) - 1u), kind = rays[i] >> SLOT_BITS;
-                        if (s >= n_slots || kind > 2 || fresh_ids[i] >= nctx) { err("garbage ray-ring entry"); continue; }
-                        Ctx& c = ctx[fresh_ids[i]];
-                        c.slot = s; c.kind = kind; c.ident = slots[s].pushed[kind];
-                        c.node_steps = 1u + hash32(c.ident) % 6u;
-                        c.tri_steps = hash32(c.ident + 99u) % 4u;
-                        to_nq[n_nq++] = fresh_ids[i];      // (the root step is the next hop)
-                    }
-                }
-            }
-            push(sq, to_sq, n_sq);
-            push(fl, to_fl, n_fl);
-            push(tq, to_tq, n_tq);
-            push(nq, to_nq, n_nq);
         }
     }
 
@@ -311,18 +234,13 @@ struct Model {
         }
     }
 
-    int run(uint32_t tracers, uint32_t shaders, uint32_t rq_log2, uint32_t nctx_log2) {
+    int run(uint32_t tracers, uint32_t shaders, uint32_t rq_log2) {
         slots.assign(n_slots, Slot());
         pixels = std::vector<Pixel>(n_pixels);
         s_wait.assign(n_slots, 0u);
         uint32_t sq_log2 = 0;
         while ((1u << sq_log2) < n_slots) sq_log2++;
         rq.init(rq_log2); sq.init(sq_log2);
-        nctx = 1u << nctx_log2;
-        ctx.assign(nctx, Ctx());
-        nq.init(nctx_log2); tq.init(nctx_log2); fl.init(nctx_log2);
-        for (uint32_t i = 0; i < nctx; i++) fl.cells[i] = ER_RING_FULL | i;
-        fl.ctl[ER_RING_TAIL] = fl.ctl[ER_RING_COUNT] = nctx;
         px_cap = 1;
         while (px_cap < n_pixels) px_cap <<= 1;
         px_cells.assign(px_cap, 0);
@@ -341,7 +259,7 @@ struct Model {
         for (uint32_t s = 0; s < in_slots; s++) { begin_sample(s, s, n_samples); first.push_back(s); }
         rays_pushed.fetch_add(in_slots);
         std::vector<std::thread> th;
-        for (uint32_t t = 0; t < tracers; t++) th.emplace_back([this] { variant == 1 ? pool_tracer() : first_tracer(); });
+        for (uint32_t t = 0; t < tracers; t++) th.emplace_back([this] { first_tracer(); });
         for (uint32_t t = 0; t < shaders; t++) th.emplace_back([this] { shader(); });
         // (the camera rays go in while the waves already run: the model's ray ring may be smaller than the slots, the kernel's is
         // not -- static_assert in er_stream.hip -- and fills it before its waves start)
@@ -352,7 +270,7 @@ struct Model {
             while (!stop.load()) {
                 std::this_thread::sleep_for(std::chrono::seconds(1));
                 auto d = [&](const char* n, Ring& r) { fprintf(stderr, " %s t%u c%u h%u", n, er_ring_load(&r.ctl[0]), er_ring_load(&r.ctl[1]), er_ring_load(&r.ctl[2])); };
-                d("rq", rq); d("sq", sq); d("nq", nq); d("tq", tq); d("fl", fl); d("px", px);
+                d("rq", rq); d("sq", sq); d("px", px);
                 fprintf(stderr, " live %u done %u\n", er_ring_load(&live), er_ring_load(&done));
             }
         });
@@ -379,7 +297,6 @@ struct Model {
         uint32_t bad = 0;
         if (variant != 2) {
             bad += ring_clean(rq, "ray ring", 0) + ring_clean(sq, "shade ring", 0);
-            if (variant == 1) bad += ring_clean(nq, "node queue", 0) + ring_clean(tq, "triangle queue", 0) + ring_clean(fl, "free list", nctx);
             for (uint32_t w : px_bits) if (w) bad++;
         }
         if (px.ctl[ER_RING_COUNT] != 0) bad++;
@@ -400,7 +317,7 @@ int main(int argc, char** argv) {
     m.n_samples = argc > 3 ? (uint32_t)atoi(argv[3]) : 50;
     m.variant = argc > 4 ? (uint32_t)atoi(argv[4]) : 0;
     const uint32_t tracers = argc > 5 ? (uint32_t)atoi(argv[5]) : 3, shaders = argc > 6 ? (uint32_t)atoi(argv[6]) : 2;
-    const uint32_t rq_log2 = argc > 7 ? (uint32_t)atoi(argv[7]) : 3, nctx_log2 = argc > 8 ? (uint32_t)atoi(argv[8]) : 3;
-    if (m.n_slots > (1u << SLOT_BITS) || m.n_slots == 0 || m.n_pixels == 0) return 2;
-    return m.run(tracers, shaders, rq_log2, nctx_log2);
+    const uint32_t rq_log2 = argc > 7 ? (uint32_t)atoi(argv[7]) : 3;
+    if (m.n_slots > (1u << SLOT_BITS) || m.n_slots == 0 || m.n_pixels == 0 || (m.variant != 0 && m.variant != 2)) return 2;
+    return m.run(tracers, shaders, rq_log2);
 }

@@ -7,6 +7,9 @@ A one-GPU box cannot run RCCL with more than one rank (RCCL refuses two ranks on
     size 1.  The N-GPU run is bench.py --gpus N, which the driver launches on a whole node.
 """
 import ctypes as C
+import os
+
+os.environ.setdefault("ER_LOCAL_RECV_TIMEOUT_S", "2")      # (read once by the library: how long an in-process receive waits for its send)
 
 import numpy as np
 import pytest
@@ -55,7 +58,7 @@ def test_gather_pass_over_the_loopback_transport_reassembles_the_frame(sched):
     assert (other.view(np.uint32) != full["beauty"].view(np.uint32)).any()
     # the root before its peers have sent: a state error, not a hang
     assert lib.er_gather_pass(rms[root].handle, 0, comms[root], root) == abi.ER_ERR_STATE
-    assert b"has not sent yet" in lib.er_last_error()
+    assert b"has not sent within" in lib.er_last_error()
     # rank / world of scene and communicator must match
     assert lib.er_gather_pass(rms[0].handle, 0, comms[2], root) == abi.ER_ERR_INVALID_ARG
     for rm in rms:

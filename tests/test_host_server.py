@@ -135,7 +135,8 @@ def test_recorded_session_on_the_gpu_equals_direct_and_oracle_renders(tmp_path, 
     devs = c.get_sycl_info()["devices"]
     assert devs and devs[0]["is_compatible"] and devs[0]["type"] == "gpu"
     img = client.play_cornell_session(c, a, sample_target=6, device=f'{devs[0]["name"]}|{devs[0]["platform"]}')
-    assert c.get_info() == {"samples": 7}
+    info = c.get_info()
+    assert info["samples"] == 7 and info["gpus"] == 1 and info["samples_per_call"] >= 1
     normal = c.get_pass("normal", 48, 48)
     unknown = c.get_pass("no_such_pass", 48, 48)                     # parsePass: unknown names -> BEAUTY (src/kernel.cpp:50-73)
     assert (unknown.view(np.uint32) == img.view(np.uint32)).all()
@@ -156,3 +157,51 @@ def test_recorded_session_on_the_gpu_equals_direct_and_oracle_renders(tmp_path, 
     ref = o.read_pass(0)
     o.close()
     assert (img.view(np.uint32) == ref.view(np.uint32)).all(-1).mean() >= 0.999
+
+
+def test_multi_gpu_config_is_validated_and_fails_cleanly_without_a_gpu():
+    """`gpus` / `devices` / `transport` of load_config (the C++ host drives several GPUs itself): bad values are refused with an
+    error reply; without a device `--start` says so instead of crashing N threads."""
+    s = Server()
+    c = client.Client(port=s.port)
+    base = dict(x_res=32, y_res=24, sample_target=2, denoise=False, device="", block_size=8)
+    for bad, text in ((dict(gpus=0), b"gpus out of range"), (dict(gpus=2, devices=[0]), b"one ordinal per gpu"), (dict(gpus=65), b"gpus out of range")):
+        t, f, d = c.command("--load_config", client.Client._json(dict(base, **bad)))
+        assert d.startswith(b"error:") and text in d, d
+    if abi.load().er_device_count() == 0:
+        with pytest.raises(client.ProtocolError) as e:
+            client.play_cornell_session(c, client.cornell_session_assets(32, 24), sample_target=2, gpus=3)
+        assert "--start" in str(e.value) and ("no HIP device" in str(e.value) or "no gfx950 device" in str(e.value))
+    c.close()
+    assert s.finish() == 0
+
+
+@pytest.mark.gpu
+def test_three_ranks_behind_one_session_equal_the_single_gpu_frame(tmp_path):
+    """north_star: the host API stays intact AND the tiles shard over the GPUs of the node.  Three ranks on this box's one GPU
+    (devices [0, 0, 0], in-process transport -- the code path of `gpus: 8` on a node, only the wire differs): every plane fetched
+    over the wire, the sample count and the denoised plane equal the one-GPU session's bit for bit."""
+    a = client.cornell_session_assets(100, 76)                       # partial tiles on both edges
+    frames = {}
+    for gpus in (1, 3):
+        s = Server()
+        c = client.Client(port=s.port)
+        extra = dict(gpus=3, devices=[0, 0, 0], transport="local") if gpus == 3 else {}
+        img = client.play_cornell_session(c, a, sample_target=5, **extra)
+        info = c.get_info()
+        assert info["samples"] == 6 and info["gpus"] == gpus
+        if gpus == 3:
+            assert info["transport"] == "in-process"
+        frames[gpus] = dict(beauty=img, normal=c.get_pass("normal", 100, 76), tangent=c.get_pass("tangent", 100, 76), denoise=c.get_pass("denoise", 100, 76))
+        c.close()
+        assert s.finish() == 0
+    for k in frames[1]:
+        assert (frames[1][k].view(np.uint32) == frames[3][k].view(np.uint32)).all(), k
+    # a transport the config names but the box cannot give: refused at --start with a reason
+    s = Server()
+    c = client.Client(port=s.port)
+    with pytest.raises(client.ProtocolError) as e:
+        client.play_cornell_session(c, a, sample_target=2, gpus=2, devices=[0, 0], transport="rccl")
+    assert "one device per rank" in str(e.value)
+    c.close()
+    assert s.finish() == 0

@@ -71,14 +71,12 @@ def test_cornell_obj_round_trip(tmp_path):
     tang = c[:, :, 8:11]
     assert np.allclose(np.linalg.norm(tang, axis=-1), 1.0, atol=1e-5)
     assert np.abs((tang * c[:, :, 3:6]).sum(-1)).max() < 1e-5
-    # every triangle has uv (0,0),(1,0),(0,1): dP/du is its first edge.  Corners 1 and 2 are alone in their
-    # (position, normal, uv) group and get exactly that; corner 0 is shared by the quad's two triangles with the SAME
-    # uv, so MikkTSpace-style grouping blends their two first edges, weighted by the corner angles (45 degrees each)
+    # every triangle has uv (0,0),(1,0),(0,1): dP/du is its first edge.  The two triangles of a wall share corner 0 with the SAME
+    # position, normal and uv (one welded vertex), but the diagonal they share carries different uvs on its two sides, so they
+    # are not neighbours across an edge of equal welded indices: mikktspace.c keeps them in separate groups (round 2 grouped by
+    # attribute equality alone and blended the two first edges at that corner)
     ref = sc.tangents.reshape(-1, 3, 3)
-    assert np.allclose(tang[:, 1:], ref[:, 1:], atol=1e-5)
-    pair = ref[0::2, 0] + ref[1::2, 0]
-    pair /= np.linalg.norm(pair, axis=-1, keepdims=True)
-    assert np.allclose(tang[0::2, 0], pair, atol=1e-5) and np.allclose(tang[1::2, 0], pair, atol=1e-5)
+    assert np.allclose(tang, ref, atol=1e-5)
     assert (signs == 1).all()
 
 
@@ -183,3 +181,98 @@ def test_mtl_reader_key_handling(tmp_path):
     lamp = dict(zip(out[1].split()[2::2], out[1].split()[3::2]))
     assert [float(v) for v in lamp["Ke"].split(",")] == pytest.approx([5, 4, 3]) and lamp["refl"] == "env.hdr" and lamp["map_Ns"] == "gloss.png"
     assert float(lamp["opacity"]) == 1.0 and float(lamp["specular"]) == 0.5      # Material defaults (src/Material.h:20-47)
+
+
+def _dump(tmp_path, name, text):
+    path = str(tmp_path / name)
+    open(path, "w").write(text)
+    return parse(subprocess.check_output([build(), path], text=True))
+
+
+def _tri(f, corners, n=(0, 0, 1)):
+    """append one triangle (loaded-space positions, uv) to OBJ text f; returns nothing (positions are written z-negated)"""
+    for (p, uv) in corners:
+        f.append("v %.9g %.9g %.9g\nvt %.9g %.9g\nvn %.9g %.9g %.9g" % (p[0], p[1], -p[2], uv[0], uv[1], n[0], n[1], -n[2]))
+    k = len([l for l in f if l.startswith("v ")])
+    f.append("f %d/%d/%d %d/%d/%d %d/%d/%d" % (k - 2, k - 2, k - 2, k - 1, k - 1, k - 1, k, k, k))
+
+
+def test_mikktspace_mirrored_uv_quads_do_not_blend_across_the_shared_edge(tmp_path):
+    """Two quads in the plane z = 0 share the edge x = 0 with identical position, normal AND uv there, but the right quad's uv
+    square is mirrored (u = 1 - x).  mikktspace.c: neighbours across that edge, yet of different orientation, so the flood
+    (AssignRecur) stops: the left quad's corners get +x with sign +1, the right quad's -x (the direction of increasing u) with
+    sign -1 -- also at the two shared vertices."""
+    f = ["o quads"]
+    L = [((-1, 0, 0), (0, 0)), ((0, 0, 0), (1, 0)), ((0, 1, 0), (1, 1)), ((-1, 1, 0), (0, 1))]
+    R = [((0, 0, 0), (1, 0)), ((1, 0, 0), (0, 0)), ((1, 1, 0), (0, 1)), ((0, 1, 0), (1, 1))]
+    for q in (L, R):
+        _tri(f, [q[0], q[1], q[2]])
+        _tri(f, [q[0], q[2], q[3]])
+    c, signs, _ = _dump(tmp_path, "mirror.obj", "\n".join(f) + "\n")
+    assert np.allclose(c[0:2, :, 8:11], [1, 0, 0], atol=1e-6) and (signs[0:2] == 1).all()
+    assert np.allclose(c[2:4, :, 8:11], [-1, 0, 0], atol=1e-6) and (signs[2:4] == -1).all()
+
+
+def test_mikktspace_groups_need_edge_connectivity_not_just_equal_attributes(tmp_path):
+    """A bow tie: two triangles that share ONE vertex (same position, normal, uv, same orientation) and no edge.  mikktspace.c
+    grows groups across shared edges only, so each triangle keeps its own dP/du at that vertex: (1,0,0) and (0,-1,0) -- an
+    attribute-equality grouping (round 2) would have blended them to the diagonal."""
+    f = ["o bowtie"]
+    _tri(f, [((0, 0, 0), (0, 0)), ((1, 0, 0), (1, 0)), ((0, 1, 0), (0, 1))])
+    _tri(f, [((0, 0, 0), (0, 0)), ((0, -1, 0), (1, 0)), ((1, -1, 0), (0, 1))])
+    c, signs, _ = _dump(tmp_path, "bowtie.obj", "\n".join(f) + "\n")
+    assert np.allclose(c[0, :, 8:11], [1, 0, 0], atol=1e-6)
+    assert np.allclose(c[1, :, 8:11], [0, -1, 0], atol=1e-6)
+    assert (signs == 1).all()
+
+
+def test_mikktspace_degenerate_and_zero_uv_area_triangles(tmp_path):
+    """Hand-derived from mikktspace.c's rules:
+      G  good triangle, dP/du = (0,1,0): every corner (0,1,0), sign +1;
+      A  zero uv area (GROUP_WITH_ANY), neighbour of G across G's edge 1->2 with opposite winding: its two corners on that edge
+         are pulled into G's groups and get G's tangent (A itself contributes nothing); its third corner is never assigned and
+         keeps the initial space (1,0,0) / not orientation preserving -- and the triangle's ONE sign is what the last corner
+         delivered: -1;
+      D  two equal positions (degenerate): corners 0 and 1 coincide with G's vertex 1 in position, normal and uv and borrow its
+         tangent (0,1,0); corner 2 finds no good corner and keeps (1,0,0); sign of the last corner: -1;
+      Z  an isolated zero-uv-area triangle: (1,0,0) three times, sign -1."""
+    f = ["o mixed"]
+    _tri(f, [((0, 0, 0), (0, 0)), ((0, 1, 0), (1, 0)), ((-1, 0, 0), (0, 1))])                      # G
+    _tri(f, [((-1, 0, 0), (0, 1)), ((0, 1, 0), (1, 0)), ((-1, 1, 0), (0.5, 0.5))])                 # A
+    _tri(f, [((0, 1, 0), (1, 0)), ((0, 1, 0), (1, 0)), ((5, 5, 0), (3, 3))])                       # D
+    _tri(f, [((10, 0, 0), (0, 0)), ((11, 0, 0), (0.25, 0.25)), ((10, 1, 0), (0.5, 0.5))])          # Z
+    c, signs, _ = _dump(tmp_path, "mixed.obj", "\n".join(f) + "\n")
+    T = c[:, :, 8:11]
+    assert np.allclose(T[0], [[0, 1, 0]] * 3, atol=1e-6) and signs[0] == 1
+    assert np.allclose(T[1], [[0, 1, 0], [0, 1, 0], [1, 0, 0]], atol=1e-6) and signs[1] == -1
+    assert np.allclose(T[2], [[0, 1, 0], [0, 1, 0], [1, 0, 0]], atol=1e-6) and signs[2] == -1
+    assert np.allclose(T[3], [[1, 0, 0]] * 3, atol=1e-6) and signs[3] == -1
+
+
+def test_mikktspace_uv_seamed_cylinder(tmp_path):
+    """A cylinder around the y axis, smooth radial normals, u = longitude / 2 pi with the seam column duplicated (u = 0 and
+    u = 1 at the same position: different uv, so two vertices and no edge across the seam).  Away from the seam every vertex's
+    six triangles form one group and their angle-weighted dP/du is the unit east vector; at the seam each side is a half fan
+    whose tangent leans by at most half a segment."""
+    nu, nv = 20, 4
+    f = ["o cylinder"]
+    for j in range(nv + 1):
+        for i in range(nu + 1):
+            ph = 2 * np.pi * i / nu
+            p = (np.cos(ph), j / nv, np.sin(ph))
+            f.append("v %.9g %.9g %.9g\nvn %.9g %.9g %.9g\nvt %.9g %.9g" % (p[0], p[1], -p[2], p[0], 0.0, -p[2], i / nu, j / nv))
+    idx = lambda i, j: j * (nu + 1) + i + 1
+    for j in range(nv):
+        for i in range(nu):
+            a, b, c_, d = idx(i, j), idx(i + 1, j), idx(i + 1, j + 1), idx(i, j + 1)
+            f.append("f %d/%d/%d %d/%d/%d %d/%d/%d" % (a, a, a, b, b, b, c_, c_, c_))
+            f.append("f %d/%d/%d %d/%d/%d %d/%d/%d" % (a, a, a, c_, c_, c_, d, d, d))
+    c, signs, _ = _dump(tmp_path, "cyl.obj", "\n".join(f) + "\n")
+    pos, nrm, tang, uv = c[:, :, 0:3].reshape(-1, 3), c[:, :, 3:6].reshape(-1, 3), c[:, :, 8:11].reshape(-1, 3), c[:, :, 6:8].reshape(-1, 2)
+    east = np.stack([-pos[:, 2], np.zeros(len(pos)), pos[:, 0]], -1)
+    inner = (uv[:, 1] > 0.01) & (uv[:, 1] < 0.99)
+    seam = (uv[:, 0] < 1e-6) | (uv[:, 0] > 1 - 1e-6)
+    assert (np.abs((tang * nrm).sum(-1)) < 1e-5).all() and np.allclose(np.linalg.norm(tang, axis=-1), 1, atol=1e-5)
+    assert ((tang[inner & ~seam] * east[inner & ~seam]).sum(-1) > 0.99999).all()
+    assert ((tang[seam] * east[seam]).sum(-1) > np.cos(np.pi / nu) - 1e-4).all()
+    assert len(set(signs.tolist())) == 1

@@ -156,19 +156,21 @@ def main():
     text.append("unmarked (product) build, whole kernel: " + ", ".join(f"{k} {tp[k]}" for k in COLS if tp[k]) + f", total {sum(tp.values())}")
     text.append("metadata marked:   " + str(meta(marked.splitlines(), a.kernel)))
     text.append("metadata unmarked: " + str(meta(plain.splitlines(), a.kernel)))
-    # tracer loop vs shader step: spill traffic sites
+    # tracer loop vs shader loop: spill traffic sites
     tr = collections.Counter()
     sh = collections.Counter()
     for name, c in rm.items():
-        if name.startswith(("tracer_", "tri_block", "node_block", "apply_end")) and not name.startswith("tracer_loop_end"):
+        base = name.split("#")[0]
+        if base in ("tracer_loop_end", "pool_loop_end", "shader_loop_end", "epilogue", "(prologue)"):
+            continue
+        if base.startswith(("tracer_", "pool_", "tri_block", "node_block", "apply_end")):
             tr.update(c)
-        elif name.startswith(("shader_", "tracer_loop_end")):
+        elif base.startswith("shader_"):
             sh.update(c)
-    text.append("")
-    text.append(f"tracer loop (tracer_loop_top .. tracer_publish): scratch sites {tr['scratch']}, v_readlane/v_writelane sites {tr['lane_spill_move']}, "
-                f"VALU {tr['valu'] + tr['valu_pk'] + tr['valu_cvt'] + tr['valu_trans']} (packed {tr['valu_pk']}), SALU {tr['salu']}, LDS {tr['lds']}, VMEM {tr['vmem']}")
-    text.append(f"shader loop (shader_loop_top .. shader_loop_end):  scratch sites {sh['scratch']}, v_readlane/v_writelane sites {sh['lane_spill_move']}, "
-                f"VALU {sh['valu'] + sh['valu_pk'] + sh['valu_cvt'] + sh['valu_trans']} (packed {sh['valu_pk']}), SALU {sh['salu']}, LDS {sh['lds']}, VMEM {sh['vmem']}")
+    for label, c in (("tracer loop", tr), ("shader loop", sh)):
+        text.append(f"{label}: scratch sites {c['scratch']}, v_readlane/v_writelane sites {c['lane_spill_move']}, "
+                    f"VALU {c['valu'] + c['valu_pk'] + c['valu_cvt'] + c['valu_trans']} (packed {c['valu_pk']}, cvt {c['valu_cvt']}, transcendental {c['valu_trans']}), "
+                    f"SALU {c['salu']}, LDS {c['lds']}, VMEM {c['vmem']}, branches {c['branch']}, waits {c['wait']}")
     s = "\n".join(text)
     print(s)
     if a.out:
