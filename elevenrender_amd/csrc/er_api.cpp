@@ -287,7 +287,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             cus = std::max(1, cus);
             if (px < 150000u) sched = ER_FLAG_FUSED;
             else if (px > 4000000u && s->tri_count > 4000000u) sched = ER_FLAG_WAVEFRONT;
-            else if ((owned.size() + (size_t)cus - 1) / (size_t)cus * 64u > ER_STREAM_MAX_RING) sched = ER_FLAG_WAVEFRONT;     // (beyond the streaming schedule's pixel rings)
+            else if (((owned.size() + (size_t)cus - 1) / (size_t)cus + 4u) * 64u > ER_STREAM_MAX_RING) sched = ER_FLAG_WAVEFRONT;     // (beyond the streaming schedule's pixel rings)
             else sched = ER_FLAG_STREAM;
         }
         else if (forced & (forced - 1)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: more than one schedule flag");
@@ -320,8 +320,13 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         // (capacity rounded up to a power of two: positions are monotonic 32-bit counters and may wrap)
         // (no minimum beyond one tile: a producer that comes round to a cell whose entry has not been read yet waits for its
         // reader, er_ring.h -- round 2 relied on "a lap of >= 4096 cells takes longer than a read")
+        std::vector<uint32_t> deal;
+        const char* xe = getenv("ER_STREAM_XCD_TILES");        // A/B knob: 0 = tiles dealt round-robin to the workgroups (round 2)
+        const uint32_t most = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), (s->x_res + ER_TILE - 1) / ER_TILE, s->stream_blocks, !(xe && atoi(xe) == 0), deal);
+        if ((rc = upload(s->d_deal, deal.data(), deal.size(), s->stream)) != ER_OK) return rc;
+        HIP_TRY(hipStreamSynchronize(s->stream));          // (`deal` goes out of scope)
         s->stream_ring_cap = 64u;
-        while (s->stream_ring_cap < (uint32_t)((owned.size() + s->stream_blocks - 1) / s->stream_blocks) * 64u) s->stream_ring_cap <<= 1;
+        while (s->stream_ring_cap < most * 64u) s->stream_ring_cap <<= 1;
         if (s->stream_ring_cap > ER_STREAM_MAX_RING)
             return fail(ER_ERR_INVALID_ARG, "er_render_begin: ER_FLAG_STREAM serves at most " + std::to_string((size_t)ER_STREAM_MAX_RING * s->stream_blocks) +
                                                 " owned pixels per rank; use ER_FLAG_WAVEFRONT (the automatic choice does)");
@@ -476,7 +481,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     if (s->params.flags & ER_FLAG_FUSED) {
         er_launch_fused(s->dev, s->d_ticket.p, s->d_spill.p, n, count, s->fused_blocks, s->stream);
     } else if (s->params.flags & ER_FLAG_STREAM) {
-        er_launch_stream(s->dev, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
+        er_launch_stream(s->dev, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_deal.p, (uint32_t)s->d_deal.n, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
                          s->stream_blocks, s->stream_tracers, s->stream);
     } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
         er_launch_render(s->dev, n, count, s->stream);

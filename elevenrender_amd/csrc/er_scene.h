@@ -178,7 +178,7 @@ struct ErScene {
     DevBuf<float4> d_wf4;        // 11 float4 arrays of the wavefront state, back to back
     DevBuf<uint32_t> d_wf1;      // hit, left, occluded, 4 queues, counts
     DevBuf<uint2> d_spill;
-    DevBuf<uint32_t> d_guide, d_ticket;
+    DevBuf<uint32_t> d_guide, d_ticket, d_deal;      // d_deal: the streaming schedule's deal of tiles to workgroups (er_stream_deal_tiles)
     uint32_t fused_blocks = 0;
     uint32_t stream_blocks = 0, stream_tracers = 0, stream_ring_cap = 0;     // streaming schedule (er_stream.hip): workgroups; tracer waves of the 16
     bool stream_lights = false;                         //   slot records carry the point-light query's line
@@ -209,7 +209,7 @@ struct ErScene {
     void release_device() {
         d_nodes.release(); d_nodes8.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_materials.release();
         d_textures.release(); d_tex_pool.release(); d_lights.release(); d_cdf.release(); d_samples.release(); d_rng.release();
-        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_ray_log.release();
+        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_deal.release(); d_ray_log.release();
         for (auto& kv : d_rank_tiles) kv.second.release();
         d_rank_tiles.clear();
         for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <vector>
+
 struct DevScene;
 struct WfState;
 
@@ -18,10 +20,12 @@ struct WfState;
 
 // records: slots * er_stream_record_bytes(lights) bytes (slots = blocks * ER_STREAM_SLOTS; lights: the scene uses the point-light
 // extension, whose queries take a third line per slot); spill: er_stream_spill_entries(blocks) uint2 entries; ring:
-// blocks * ring_cap uint2 entries (the workgroups' pixel rings; ring_cap = a power of two >= 64 * ceil(owned tiles / blocks) and
+// blocks * ring_cap uint2 entries (the workgroups' pixel rings; ring_cap = a power of two >= 64 * er_stream_deal_tiles(...) and
 // <= ER_STREAM_MAX_RING); status: one word, 0 unless a wave's watchdog or a ring guard fired.
-void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, void* ring, uint32_t ring_cap, uint32_t* status,
-                      uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream);
+void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
+                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream);
+// the deal of the owned tiles to the workgroups (device copy of `out` = `deal` above, deal_count = out.size()); returns the most tiles of one workgroup
+uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, bool xcd_aware, std::vector<uint32_t>& out);
 uint32_t er_stream_record_bytes(bool lights);
 size_t er_stream_spill_entries(uint32_t blocks);
 hipError_t er_probe_stream(const char** which);

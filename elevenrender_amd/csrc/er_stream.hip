@@ -29,7 +29,10 @@
 //
 // Every wave leaves its loop when the workgroup's last slot has retired (s_ctl[C_DONE]); a wave that sees no progress for
 // ~0.2 s, or whose ring wait outlasts ER_RING_GUARD polls, raises the status word and ends the workgroup (it cannot hang).
+#include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <vector>
 #include "er_device.h"
 #include "er_kernels.h"
 #include "er_wavefront.h"
@@ -52,7 +55,7 @@ static_assert(ER_STREAM_SLOTS <= (1u << ST_SLOT_BITS) && ST_SLOT_BITS + 2 <= ER_
 // to drain the ray ring -- which they do whatever the shaders are doing -- never the other way round: the shade ring holds
 // a slot at most once, so ER_STREAM_SLOTS cells can never be full), so capacities are a tuning matter, not a safety margin.
 #define ST_RQ_LOG2 12u
-#define ST_SQ_LOG2 10u
+#define ST_SQ_LOG2 (ER_STREAM_SLOTS > 1024u ? 11u : 10u)
 static_assert((1u << ST_SQ_LOG2) >= ER_STREAM_SLOTS, "the shade ring must hold every slot once");
 // a wave's reservation (<= 3 x 64 entries) must fit the ring several times over (a reservation longer than the ring would wait for
 // readers of its own unpublished entries), and the camera rays of all slots go in before the waves start
@@ -179,11 +182,14 @@ struct StState {
 #define ST_LAP_TAG(pos, cap) (((((pos) / (cap)) & 0x7Fu) + 1u) << 24)
 #define ST_LEFT_MASK 0x00FFFFFFu
 
-// pixel k of workgroup b's share: tile b + (k / 64) * workgroups of the owned tiles, lane k % 64 (false: outside the image)
-__device__ __forceinline__ bool st_pixel_of(const DevScene& S, uint32_t b, uint32_t nb, uint32_t k, uint32_t& px, uint32_t& py) {
+// pixel k of workgroup b's share: entry b + (k / 64) * workgroups of the deal (er_stream_deal_tiles below), lane k % 64
+// (false: no tile there, or outside the image)
+__device__ __forceinline__ bool st_pixel_of(const DevScene& S, const uint32_t* deal, uint32_t deal_count, uint32_t b, uint32_t nb, uint32_t k, uint32_t& px,
+                                            uint32_t& py) {
     const uint32_t t = b + (k >> 6) * nb, l = k & 63u;
-    if (t >= S.owned_tile_count) return false;
-    const uint32_t tile = S.owned_tiles[t];
+    if (t >= deal_count) return false;
+    const uint32_t tile = deal[t];
+    if (tile == 0xFFFFFFFFu) return false;
     px = (tile % S.tiles_x) * ER_TILE + (l & 7u);
     py = (tile / S.tiles_x) * ER_TILE + (l >> 3);
     return px < S.x_res && py < S.y_res;
@@ -221,8 +227,8 @@ __device__ __forceinline__ void st_write_result(const StState& W, uint32_t rec, 
 }  // namespace
 
 template <bool COUNT, bool EXT>
-__global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StState W, uint2* ring_base, uint32_t ring_cap, uint32_t* status,
-                                                          uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min) {
+__global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StState W, const uint32_t* deal, uint32_t deal_count, uint2* ring_base, uint32_t ring_cap,
+                                                          uint32_t* status, uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min) {
     constexpr uint32_t RQ_LOG2 = ST_RQ_LOG2, SLOTS = ER_STREAM_SLOTS, TOP_NODES = ER_STREAM_TOP_NODES;
     __shared__ uint32_t s_rq[1u << RQ_LOG2];
     __shared__ uint32_t s_sq[1u << ST_SQ_LOG2];
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
     for (uint32_t k0 = 0; k0 < ring_cap; k0 += ST_THREADS) {
         const uint32_t k = k0 + threadIdx.x;
         uint32_t px = 0, py = 0;
-        const bool valid = n_samples > 0 && k < ring_cap && st_pixel_of(S, blockIdx.x, gridDim.x, k, px, py);
+        const bool valid = n_samples > 0 && k < ring_cap && st_pixel_of(S, deal, deal_count, blockIdx.x, gridDim.x, k, px, py);
         const uint32_t v = st_reserve(&s_ctl[C_INIT], valid);      // (rank among the valid pixels; order does not matter)
         const bool to_slot = valid && v < SLOTS;
         const uint32_t idx = py * S.x_res + px;
@@ -650,8 +656,39 @@ hipError_t er_probe_stream(const char** which) {
     return hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false>);
 }
 
-void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, void* ring, uint32_t ring_cap, uint32_t* status,
-                      uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream) {
+// Which workgroup renders which tiles.  Workgroups b and b + 8 run on the same XCD and share its 4 MB L2 (observed dispatch
+// order, MI355X_MICROARCH.md; used for speed only -- any deal gives the same pixels), so the frame is cut into super-tiles of
+// 8 x 8 tiles (64 x 64 pixels), every super-tile goes to ONE XCD (the one with the fewest tiles so far), and inside an XCD the
+// tiles are dealt round-robin to its workgroups: the camera rays and first bounces that an L2 serves then come from a few
+// compact screen regions instead of from every eighth tile of the whole frame.  out[b + k * blocks] = the k-th tile of
+// workgroup b, 0xFFFFFFFF = none; returns the largest number of tiles any workgroup got.
+uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, bool xcd_aware, std::vector<uint32_t>& out) {
+    const uint32_t X = (xcd_aware && blocks % 8u == 0u) ? 8u : 1u, per = blocks / X, S8 = 8u;
+    const uint32_t super_x = (tiles_x + S8 - 1u) / S8;
+    std::map<uint32_t, std::vector<uint32_t>> by_super;      // row-major super-tile order; tiles inside keep their row-major order
+    for (uint32_t i = 0; i < count; i++) {
+        const uint32_t tx = owned[i] % tiles_x, ty = owned[i] / tiles_x;
+        by_super[X == 1u ? 0u : (ty / S8) * super_x + tx / S8].push_back(owned[i]);
+    }
+    std::vector<std::vector<uint32_t>> seq(X);
+    for (auto& kv : by_super) {
+        uint32_t best = 0;
+        for (uint32_t x = 1; x < X; x++) if (seq[x].size() < seq[best].size()) best = x;
+        seq[best].insert(seq[best].end(), kv.second.begin(), kv.second.end());
+    }
+    uint32_t maxk = 0;
+    for (uint32_t x = 0; x < X; x++) maxk = std::max<uint32_t>(maxk, (uint32_t)((seq[x].size() + per - 1u) / per));
+    out.assign((size_t)blocks * maxk, 0xFFFFFFFFu);
+    for (uint32_t x = 0; x < X; x++)
+        for (size_t sidx = 0; sidx < seq[x].size(); sidx++) {
+            const uint32_t j = (uint32_t)(sidx % per), k = (uint32_t)(sidx / per), b = j * X + x;      // b % X == x: the XCD
+            out[(size_t)b + (size_t)k * blocks] = seq[x][sidx];
+        }
+    return maxk;
+}
+
+void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
+                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream) {
     static const uint32_t refill_min = [] {
         const char* e = getenv("ER_STREAM_REFILL_MIN");
         int v = e ? atoi(e) : 12;
@@ -670,7 +707,7 @@ void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lig
     st.spill = (uint2*)spill;
     st.slots = slots;
     st.stride = er_stream_record_bytes(lights);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(ST_THREADS), 0, stream, S, st, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(ST_THREADS), 0, stream, S, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min);
 }
 
 uint32_t er_stream_record_bytes(bool lights) { return lights ? ST_STRIDE_LIGHTS : ST_STRIDE_PLAIN; }
