@@ -322,7 +322,10 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         // reader, er_ring.h -- round 2 relied on "a lap of >= 4096 cells takes longer than a read")
         std::vector<uint32_t> deal;
         const char* xe = getenv("ER_STREAM_XCD_TILES");        // A/B knob: 0 = tiles dealt round-robin to the workgroups (round 2)
-        const uint32_t most = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), (s->x_res + ER_TILE - 1) / ER_TILE, s->stream_blocks, !(xe && atoi(xe) == 0), deal);
+        // (a share with no more pixels than slots -- an eighth of a 1080p frame -- has nothing waiting in its pixel rings; there the
+        // plain round-robin deal balances a little better: 1.392 vs 1.41 ms per pass, profiles/r03_ab_sim_world8_knobs.log)
+        const bool xcd_aware = xe ? atoi(xe) != 0 : owned.size() * 64 > (size_t)s->stream_blocks * ER_STREAM_SLOTS;
+        const uint32_t most = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), (s->x_res + ER_TILE - 1) / ER_TILE, s->stream_blocks, xcd_aware, deal);
         if ((rc = upload(s->d_deal, deal.data(), deal.size(), s->stream)) != ER_OK) return rc;
         HIP_TRY(hipStreamSynchronize(s->stream));          // (`deal` goes out of scope)
         s->stream_ring_cap = 64u;

@@ -267,22 +267,22 @@ def test_streaming_schedule_long_calls_complete():
     assert (samples == 69).mean() > 0.999
 
 
-def test_streaming_schedule_repeats_on_a_small_frame():
-    """Regression for two timing-dependent faults of the streaming schedule that only small frames showed (64 pixels per
-    workgroup: its rings turn over in microseconds): a cell of the pixel ring cleared late over a fresh entry, and a slot
-    retiring during another wave's transient dip of the ring count, leaving its pixel behind -- one pixel one sample short in
-    one run of ~50.  Eighty runs, each the wavefront schedule's frame bit for bit and every path counted."""
+def test_streaming_schedule_small_frame_call_patterns():
+    """Regression run for the two call patterns in which round 2's ring protocol failed on small frames (64 pixels per workgroup:
+    the pixel ring turns over in microseconds): one call, and a short call followed by a longer one.  ONE render each -- the
+    argument that the protocol is exact is not this test but the host-thread model of the same ring functions under
+    ThreadSanitizer (tests/test_stream_protocol_cpu.py, csrc/er_ring.h); a GPU loop would only show absence of evidence."""
     sc = scenes.blob_instances(n_instances=40, tris_per_blob=300, x_res=96, y_res=72, grid=(5, 4, 2), spacing=0.45)
     ref = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_WAVEFRONT)
-    for i in range(80):
-        g = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_STREAM, chunks=None if i % 2 else [2, 5])
-        assert (g["beauty"].view(np.uint32) == ref["beauty"].view(np.uint32)).all(), i
-        assert (g["rng"] == ref["rng"]).all() and (g["samples"] == ref["samples"]).all(), i
-        assert g["counters"]["paths"] == ref["counters"]["paths"], i
+    for chunks in (None, [2, 5]):
+        g = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_STREAM, chunks=chunks)
+        assert (g["beauty"].view(np.uint32) == ref["beauty"].view(np.uint32)).all(), chunks
+        assert (g["rng"] == ref["rng"]).all() and (g["samples"] == ref["samples"]).all(), chunks
+        assert g["counters"]["paths"] == ref["counters"]["paths"], chunks
 
 
 def test_streaming_schedule_many_turns_of_the_pixel_ring():
-    """er_stream.hip: a workgroup holds 2048 of its pixels in slots and the others in a ring that every finished sample goes
+    """er_stream.hip: a workgroup holds 1024 of its pixels in slots and the others in a ring that every finished sample goes
     through.  1024x768 = 3072 pixels per workgroup: the ring turns over once per sample, 24 times here (its positions wrap
     its capacity several times), in one call and in uneven chunks -- bit for bit the wavefront schedule's frame."""
     sc = scenes.soup(50_000, 1024, 768, seed=21, hdri_size=(256, 128))
