@@ -22,6 +22,10 @@
 #define ER_MARK(name) ((void)0)
 #endif
 
+#ifndef ER_TP
+#define ER_TP(n) ((void)0)       // section stamp of the streaming kernel's diagnostic build (-DER_TIME_PROBE), nothing otherwise
+#endif
+
 #define ER_TILE 8                 // 8x8 pixel tile = one 64-lane wavefront
 #define ER_STACK ER_BVH_MAX_DEPTH
 

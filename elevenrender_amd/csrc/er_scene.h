@@ -238,8 +238,12 @@ namespace erh {
 
 // guide table of er_cdf.h: guide[j] = first i in [0,length] with cdf[i] >= j/buckets
 inline int er_build_cdf_guide(const float* cdf, int length, std::vector<uint32_t>& guide) {
+    // entries per bucket on average (buckets = a power of two >= length / per): every halving takes one dependent load off the
+    // CDF search of every shading step and doubles the table (4 bytes per bucket).  C2 (2048x1024 HDRI): 8 -> 1362 / 1367,
+    // 2 -> 1374 / 1375, 1 -> 1373 / 1372 Msamples/s on one box (profiles/r03_ab_cdf_buckets.log): 2 (a 4 MB table there).
+    static const int per = [] { const char* e = getenv("ER_CDF_ENTRIES_PER_BUCKET"); int v = e ? atoi(e) : 2; return v < 1 ? 1 : v; }();
     int buckets = 1;
-    while (buckets < length / 8 && buckets < (1 << 22)) buckets <<= 1;
+    while (buckets < length / per && buckets < (1 << 22)) buckets <<= 1;
     guide.assign((size_t)buckets + 1, (uint32_t)length);
     int i = 0;
     for (int j = 0; j <= buckets; j++) {

@@ -43,6 +43,23 @@
 
 using namespace erd;
 
+// Diagnostic build (-DER_TIME_PROBE, tools/shader_sections.py): the shader waves stamp s_memtime at section boundaries and lane 0 adds
+// the cycles since the previous stamp to one of ten per-workgroup LDS sums, flushed into the (otherwise meaningless in this build)
+// event counters at the end.  Section n = the code between stamp n and the next stamp that executes.
+#ifdef ER_TIME_PROBE
+#define ER_TPS(n)                                                                                       \
+    {                                                                                                    \
+        const unsigned long long tp_now = __builtin_amdgcn_s_memtime();                                  \
+        if (tp_sec < 10u && (threadIdx.x & 63) == 0) atomicAdd(&s_tp[tp_sec], (unsigned)((tp_now - tp_last) >> 4)); \
+        tp_last = tp_now;                                                                                \
+        tp_sec = (n);                                                                                    \
+    }
+#undef ER_TP
+#define ER_TP(n) ER_TPS(n)
+#else
+#define ER_TPS(n) ((void)0)
+#endif
+
 namespace {
 
 #define ST_SLOT_BITS 11          // ring payloads: local slot (11 bits) | kind or flag (2 bits) = ER_RING_PAYLOAD_BITS
@@ -60,6 +77,17 @@ static_assert((1u << ST_SQ_LOG2) >= ER_STREAM_SLOTS, "the shade ring must hold e
 // a wave's reservation (<= 3 x 64 entries) must fit the ring several times over (a reservation longer than the ring would wait for
 // readers of its own unpublished entries), and the camera rays of all slots go in before the waves start
 static_assert((1u << ST_RQ_LOG2) >= ER_STREAM_SLOTS && (1u << ST_RQ_LOG2) >= 4u * 192u, "ray ring too small");
+// Static issue priority (s_setprio once, before the loop: arbitration between the waves of a SIMD is by priority, then age).  A
+// shading step is ~6 000 vector instructions on a SIMD it shares with two or three tracer waves and was 138 k cycles long
+// (profiles/r03_shader_sections_c2.log); with the shader waves at priority 1 five of them feed eleven tracer waves:
+// C2 1 367 -> 1 396, C5 983 -> 1 037, 4K 1 417 -> 1 435, 720p 1 283 -> 1 276 Msamples/s (profiles/r03_ab_wave_priority_*.log; at 10 + 6
+// the same priority LOSES 6 %: the tracers then wait for issue slots).  Tracer waves at priority 1 instead: +1 %.
+#ifndef ER_SHADER_PRIO
+#define ER_SHADER_PRIO 1         // s_setprio of the shader waves / of the tracer waves for their whole loops (0 = leave it)
+#endif
+#ifndef ER_TRACER_PRIO
+#define ER_TRACER_PRIO 0
+#endif
 #ifndef ST_THREADS
 #define ST_THREADS 1024          // 16 waves per CU: four per SIMD, 128 VGPRs each
 #endif
@@ -236,6 +264,10 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
     __shared__ uint32_t s_pxbits[ST_PXBITS_WORDS];
     __shared__ uint32_t s_rq_ctl[ER_RING_WORDS], s_sq_ctl[ER_RING_WORDS], s_px_ctl[ER_RING_WORDS], s_ctl[C_WORDS];
     __shared__ float4 s_top[TOP_NODES * ER_NODE8_PIECES];
+#ifdef ER_TIME_PROBE
+    __shared__ uint32_t s_tp[13];      // [1..9] cycles / 16 per section of the shader loop, [10] shader steps, [11] slots shaded, [12] cycles / 16 of tracer iterations
+    if (threadIdx.x < 13) s_tp[threadIdx.x] = 0;
+#endif
     for (uint32_t i = threadIdx.x; i < TOP_NODES * ER_NODE8_PIECES; i += ST_THREADS)
         s_top[i] = i < S.node8_count * ER_NODE8_PIECES ? S.nodes8[i] : make_float4(0, 0, 0, 0);
     const int lane = threadIdx.x & 63;
@@ -305,6 +337,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
             Trav T;
             trav_begin(T, f3s(0), f3(0, 0, 1), false, -1, 0.0f);
             bool busy = false;
+#if ER_TRACER_PRIO
+            __builtin_amdgcn_s_setprio(ER_TRACER_PRIO);
+#endif
             uint32_t ls = 0, kind = 0, rec = 0;   // the ray in hand: local slot, kind, index of its records (g, or g + W.slots)
             uint32_t idle = 0, progress = 0;
             while (true) {
@@ -352,6 +387,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                     continue;
                 }
                 idle = 0;
+#ifdef ER_TIME_PROBE
+                const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
+#endif
                 ER_MARK("tracer_choose");
                 bool finished = false, do_step = false;
                 TravStep st;
@@ -396,6 +434,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                     }
                     st_push<ST_SQ_LOG2>(s_sq, s_sq_ctl, last, ls | ((old & ST_FIN) ? (1u << ST_SLOT_BITS) : 0u), status, ST_ERR_SHADE);
                 }
+#ifdef ER_TIME_PROBE
+                if (lane == 0) atomicAdd(&s_tp[12], (unsigned)((__builtin_amdgcn_s_memtime() - tr0) >> 4));
+#endif
                 ER_MARK("tracer_iter_end");
             }
             ER_MARK("tracer_loop_end");
@@ -408,6 +449,13 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
         bool have = false;
         uint32_t e = 0;
         uint32_t idle = 0, spins = 0, progress = 0;
+#if ER_SHADER_PRIO
+        __builtin_amdgcn_s_setprio(ER_SHADER_PRIO);      // (static priority for the whole loop: issue arbitration is by priority, then age)
+#endif
+#ifdef ER_TIME_PROBE
+        unsigned long long tp_last = __builtin_amdgcn_s_memtime();
+        uint32_t tp_sec = 99u;      // (nothing is charged until the first stamp)
+#endif
         while (true) {
             ER_MARK("shader_loop_top");
             const uint32_t avail = er_ring_load(&s_sq_ctl[ER_RING_COUNT]);
@@ -430,6 +478,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
             }
             spins = 0;
             ER_MARK("shader_take");
+            ER_TPS(0);
             uint32_t hb = 0;
             const uint32_t granted = st_take(s_sq_ctl, 64u, hb);
             if (granted == 0) continue;          // another wave was quicker
@@ -442,6 +491,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
             bool want_pixel = false;
             uint32_t rs = 0, left_after = 0, done_idx = 0;
             ER_MARK("shader_step");
+            ER_TPS(1);
             if (have) {
                 const bool fin_only = (e >> ST_SLOT_BITS) != 0;
                 uint32_t idx = W.pix(slot);
@@ -544,6 +594,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 }
             }
             ER_MARK("shader_pixel_ring");
+            ER_TPS(7);
             // finished samples: pixel back to the tail of the pixel ring (unless that was its last sample), next pixel from the head
             if (__ballot(want_pixel)) {
                 const bool back = want_pixel && left_after > 0;
@@ -599,6 +650,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 }
             }
             ER_MARK("shader_publish");
+            ER_TPS(8);
             // the slot's records are written: publish its rays
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             {
@@ -625,10 +677,25 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 }
             }
             have = false;
+            ER_TPS(9);
+#ifdef ER_TIME_PROBE
+            if (lane == 0) { atomicAdd(&s_tp[10], 1u); atomicAdd(&s_tp[11], granted); }
+#endif
         }
         ER_MARK("shader_loop_end");
     }
     ER_MARK("epilogue");
+#ifdef ER_TIME_PROBE
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long* c = (unsigned long long*)&S.counters->node_visits;      // node_visits, tri_tests, shaded_hits, texel_fetches, hdri_samples, trace_* x 4
+        for (int i = 1; i < 10; i++) atomicAdd(&c[i - 1], (unsigned long long)s_tp[i]);
+        atomicAdd(&S.counters->paths, (unsigned long long)s_tp[10]);
+        atomicAdd(&S.counters->bounce_samples, (unsigned long long)s_tp[11]);
+        atomicAdd(&S.counters->rays, (unsigned long long)s_tp[12]);
+    }
+    return;
+#endif
     unsigned t0 = st_wave_sum(c_paths), t1 = st_wave_sum(c_bounce), t2 = st_wave_sum(c_rays), t3 = st_wave_sum(c_shaded), t4 = st_wave_sum(c_hdri);
     unsigned t5 = 0, t6 = 0, t7 = 0;
     if (COUNT) { t5 = st_wave_sum(c_nodes); t6 = st_wave_sum(c_tris); t7 = st_wave_sum(c_texels); }
@@ -663,7 +730,8 @@ hipError_t er_probe_stream(const char** which) {
 // compact screen regions instead of from every eighth tile of the whole frame.  out[b + k * blocks] = the k-th tile of
 // workgroup b, 0xFFFFFFFF = none; returns the largest number of tiles any workgroup got.
 uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, bool xcd_aware, std::vector<uint32_t>& out) {
-    const uint32_t X = (xcd_aware && blocks % 8u == 0u) ? 8u : 1u, per = blocks / X, S8 = 8u;
+    static const uint32_t edge = [] { const char* e = getenv("ER_STREAM_SUPER_TILE"); int v = e ? atoi(e) : 8; return (uint32_t)(v < 1 ? 1 : v); }();   // (A/B knob)
+    const uint32_t X = (xcd_aware && blocks % 8u == 0u) ? 8u : 1u, per = blocks / X, S8 = edge;
     const uint32_t super_x = (tiles_x + S8 - 1u) / S8;
     std::map<uint32_t, std::vector<uint32_t>> by_super;      // row-major super-tile order; tiles inside keep their row-major order
     for (uint32_t i = 0; i < count; i++) {
@@ -696,7 +764,7 @@ void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lig
     }();
     static const uint32_t batch_min = [] {
         const char* e = getenv("ER_STREAM_BATCH_MIN");
-        int v = e ? atoi(e) : 48;
+        int v = e ? atoi(e) : 64;      // (five shader waves: a step that is not full is capacity lost)
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     if (S.owned_tile_count == 0 || n_samples == 0) return;

@@ -33,6 +33,7 @@ def model_tsan(tmp_path_factory):
 
 def _run(exe, *args, timeout=300):
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    env.pop("LD_PRELOAD", None)      # (tools/sanitize_cpu.sh preloads the ASan runtime into python: not into a TSan binary)
     return subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout, env=env)
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the streaming schedule's two tracers (and of knob settings) on ONE box: bash tools/ab_pool.sh reps "ENV=.. ENV=.." "ENV=.." ...
+# A/B of environment-knob settings (tuning knobs, ELEVEN_HIP_LIB=<another build>) on ONE box, alternating: bash tools/ab_pool.sh reps "ENV=.. ENV=.." "ENV=.." ...
 reps=$1; shift
 for i in $(seq $reps); do
   for cfg in "$@"; do
