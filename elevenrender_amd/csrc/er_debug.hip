@@ -58,9 +58,11 @@ void er_launch_debug_trace(const DevScene& S, const float* o, const float* d, ui
 // ---- per-bounce trace of one pixel-sample: er_bounce.inc over the production traversal, queries traced at once ----
 template <bool EXT>
 __global__ __launch_bounds__(64) void er_debug_pixel_kernel(DevScene S, uint32_t idx, ErTraceRec* recs, int max_recs, int* count, uint2* spill) {
-    // (one lane, speed irrelevant: all three traversal stacks live in the HBM scratch buffer)
-    uint2* s_stack = spill + (size_t)ER_STACK * 64;
-    int* s_stack2 = (int*)(s_stack + (size_t)WF_LDS_STACK * 64);
+    // (one lane, speed irrelevant.  The first levels of the traversal stack live in LDS as in the production kernels -- trav_choose
+    // addresses them as LDS -- the deeper levels and the exact re-trace's stack in the HBM scratch buffer)
+    __shared__ uint2 sh_stack[WF_LDS_STACK * 64];
+    uint2* s_stack = sh_stack;
+    int* s_stack2 = (int*)(spill + (size_t)ER_STACK * 64);
     if (threadIdx.x != 0) return;
     int nrec = 0;
     unsigned c_rays = 0, c_nodes = 0, c_tris = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;

@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64, FUSED_WAVES) void er_fused_kernel(DevScene S, u
     int* stack2 = (int*)(spill_base + (size_t)gridDim.x * (ER_STACK * 64)) + (size_t)blockIdx.x * (ER_STACK * 64) + lane;
     float* park = s_park + lane;
     float* aov = s_aov + lane;
-    volatile int* mail = s_mail;
+    volatile __attribute__((address_space(3))) int* mail = (volatile __attribute__((address_space(3))) int*)s_mail;      // (explicitly LDS: a volatile access through a generic pointer is a flat_load)
     s_mail[lane] = 0;
     const uint32_t n_slots = S.owned_tile_count * 64u;
     unsigned c_paths = 0, c_bounce = 0, c_rays = 0, c_nodes = 0, c_tris = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;

@@ -50,9 +50,12 @@ ER_RING_FN void er_ring_pause() { std::this_thread::yield(); }
 #include <hip/hip_runtime.h>
 #define ER_RING_FN __device__ __forceinline__
 // LDS words: volatile accesses are single ds_read / ds_write instructions, LDS operations of one wave execute in order and
-// all waves of the workgroup see one LDS
-ER_RING_FN uint32_t er_ring_load(const uint32_t* p) { return *(const volatile uint32_t*)p; }
-ER_RING_FN void er_ring_store(uint32_t* p, uint32_t v) { *(volatile uint32_t*)p = v; }
+// all waves of the workgroup see one LDS.  The pointers are cast to the LDS address space explicitly: a volatile access through
+// a generic pointer is compiled to flat_load / flat_store (the address-space inference leaves volatile accesses alone), which
+// take the vector-memory path to LDS and make every later wait of the wave a full one.
+typedef __attribute__((address_space(3))) uint32_t er_lds_u32;
+ER_RING_FN uint32_t er_ring_load(const uint32_t* p) { return *(const volatile er_lds_u32*)p; }
+ER_RING_FN void er_ring_store(uint32_t* p, uint32_t v) { *(volatile er_lds_u32*)p = v; }
 ER_RING_FN uint32_t er_ring_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 ER_RING_FN uint32_t er_ring_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 ER_RING_FN uint32_t er_ring_and(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t g0 = blockIdx.x * SLOTS;          // this workgroup's first slot
-    volatile uint32_t* v_ctl = s_ctl;
+    volatile er_lds_u32* v_ctl = (volatile er_lds_u32*)s_ctl;      // (explicitly LDS: see er_ring.h)
     const unsigned long long below = (1ull << lane) - 1ull;
 
     // ---- start: empty rings (every cell = lap 0, empty), then every slot takes a pixel and queues its first camera ray ----

@@ -89,7 +89,15 @@ ERD bool trav_choose(Trav& T, const DevScene& S, uint2* stack, uint2* spill, Tra
     if ((T.tg_mask & 0xffffu) == 0) {
         if ((T.ng_bits & 0xffu) == 0 && T.sp > 0) {
             T.sp--;
-            uint2 g = T.sp < WF_LDS_STACK ? stack[T.sp * 64] : spill[(T.sp - WF_LDS_STACK) * 64];
+            // (two typed accesses -- the first levels live in LDS in every schedule -- never a select between an LDS and an HBM
+            // pointer: that compiles to flat_load / flat_store, which go down both memory paths and make every later wait a full one)
+            uint2 g;
+            if (T.sp < WF_LDS_STACK) {
+                const unsigned long long w = *(volatile __attribute__((address_space(3))) unsigned long long*)(stack + T.sp * 64);
+                g = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+            } else {
+                g = spill[(T.sp - WF_LDS_STACK) * 64];
+            }
             T.ng_base = g.x;
             T.ng_bits = g.y;
         }
@@ -102,7 +110,8 @@ ERD bool trav_choose(Trav& T, const DevScene& S, uint2* stack, uint2* spill, Tra
             uint32_t child = T.ng_base + __popc(imask & ((1u << s8) - 1u));
             if (nmask) {                       // siblings still to visit: one stack entry for the whole group
                 uint2 g = make_uint2(T.ng_base, nmask | (imask << 8));
-                if (T.sp < WF_LDS_STACK) stack[T.sp * 64] = g; else spill[(T.sp - WF_LDS_STACK) * 64] = g;
+                if (T.sp < WF_LDS_STACK) *(volatile __attribute__((address_space(3))) unsigned long long*)(stack + T.sp * 64) = (unsigned long long)g.x | ((unsigned long long)g.y << 32);
+                else spill[(T.sp - WF_LDS_STACK) * 64] = g;
                 T.sp++;
             }
             T.ng_bits = 0;
