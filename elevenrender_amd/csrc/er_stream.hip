@@ -132,7 +132,7 @@ __device__ __forceinline__ uint32_t st_reserve(uint32_t* counter, bool want) {
     const unsigned leader = __ffsll((long long)mask) - 1;
     uint32_t base = 0;
     if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader, 64);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);      // (v_readlane: no LDS round trip, unlike __shfl = ds_bpermute)
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
 
@@ -146,7 +146,7 @@ __device__ __forceinline__ void st_push(uint32_t* cells, uint32_t* ctl, bool wan
     const uint32_t n = (uint32_t)__popcll(m);
     uint32_t base = 0;
     if (lane == 0) base = er_ring_reserve(ctl, n);
-    base = __shfl(base, 0, 64);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
     if (want && !er_ring_put(cells, LOG2, base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)), payload)) atomicOr(status, err);
     if (lane == 0) er_ring_publish(ctl, n);      // after the cells: the LDS operations of a wave execute in order
 }
@@ -155,8 +155,8 @@ __device__ __forceinline__ void st_push(uint32_t* cells, uint32_t* ctl, bool wan
 __device__ __forceinline__ uint32_t st_take(uint32_t* ctl, uint32_t want, uint32_t& base) {
     uint32_t granted = 0, hb = 0;
     if ((threadIdx.x & 63) == 0 && want > 0) granted = er_ring_grant(ctl, want, hb);
-    base = __shfl(hb, 0, 64);
-    return __shfl(granted, 0, 64);
+    base = (uint32_t)__builtin_amdgcn_readlane((int)hb, 0);
+    return (uint32_t)__builtin_amdgcn_readlane((int)granted, 0);
 }
 
 // The slot records of the wavefront schedule (er_wavefront.h: the same fields with the same meaning), laid out slot by slot.
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the pixel's planes and RNG state first, then its entry
                     uint32_t base = 0;
                     if (lane == 0) base = er_ring_reserve(s_px_ctl, (uint32_t)__popcll(mb));
-                    base = __shfl(base, 0, 64);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
                     if (back) {
                         const uint32_t pos = base + (uint32_t)__popcll(mb & below), cell = pos & (ring_cap - 1u);
                         if (!er_bits_acquire(s_pxbits, cell)) atomicOr(status, ST_ERR_PIXEL);      // (waits while the previous lap's entry is unread)
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 if (nc + ns + nl) {
                     uint32_t base = 0;
                     if (lane == 0) base = er_ring_reserve(s_rq_ctl, nc + ns + nl);
-                    base = __shfl(base, 0, 64);
+                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
                     bool ok = true;
                     if (push_closest) ok = er_ring_put(s_rq, RQ_LOG2, base + (uint32_t)__popcll(mc & below), ls) && ok;
                     if (push_shadow) ok = er_ring_put(s_rq, RQ_LOG2, base + nc + (uint32_t)__popcll(ms & below), ls | (1u << ST_SLOT_BITS)) && ok;
