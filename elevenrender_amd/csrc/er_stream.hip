@@ -152,9 +152,9 @@ __device__ __forceinline__ void st_push(uint32_t* cells, uint32_t* ctl, bool wan
 }
 
 // a wave is granted min(want, published entries) positions of a ring (all lanes call; wave-uniform result)
-__device__ __forceinline__ uint32_t st_take(uint32_t* ctl, uint32_t want, uint32_t& base) {
+__device__ __forceinline__ uint32_t st_take(uint32_t* ctl, uint32_t want, uint32_t& base, unsigned long long seen) {
     uint32_t granted = 0, hb = 0;
-    if ((threadIdx.x & 63) == 0 && want > 0) granted = er_ring_grant(ctl, want, hb);
+    if ((threadIdx.x & 63) == 0 && want > 0) granted = er_ring_grant(ctl, want, hb, seen);
     base = (uint32_t)__builtin_amdgcn_readlane((int)hb, 0);
     return (uint32_t)__builtin_amdgcn_readlane((int)granted, 0);
 }
@@ -262,7 +262,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
     __shared__ uint32_t s_sq[1u << ST_SQ_LOG2];
     __shared__ uint32_t s_wait[SLOTS];
     __shared__ uint32_t s_pxbits[ST_PXBITS_WORDS];
-    __shared__ uint32_t s_rq_ctl[ER_RING_WORDS], s_sq_ctl[ER_RING_WORDS], s_px_ctl[ER_RING_WORDS], s_ctl[C_WORDS];
+    __shared__ __attribute__((aligned(8))) uint32_t s_rq_ctl[ER_RING_WORDS], s_sq_ctl[ER_RING_WORDS], s_px_ctl[ER_RING_WORDS];
+    __shared__ uint32_t s_ctl[C_WORDS];
     __shared__ float4 s_top[TOP_NODES * ER_NODE8_PIECES];
 #ifdef ER_TIME_PROBE
     __shared__ uint32_t s_tp[13];      // [1..9] cycles / 16 per section of the shader loop, [10] shader steps, [11] slots shaded, [12] cycles / 16 of tracer iterations
@@ -347,9 +348,10 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 // idle lanes take rays from the ring; skipped while fewer than refill_min lanes are idle (it costs the whole wave ~40
                 // instructions and, when rays are taken, a pair of dependent loads) or the ring has nothing published
                 const unsigned long long bm0 = __ballot(busy);
-                if ((64u - (unsigned)__popcll(bm0) >= refill_min || bm0 == 0) && er_ring_load(&s_rq_ctl[ER_RING_COUNT]) > 0) {
+                unsigned long long rq_peek = 0;
+                if ((64u - (unsigned)__popcll(bm0) >= refill_min || bm0 == 0) && er_ring_peek_count(rq_peek = er_ring_peek(s_rq_ctl)) > 0) {
                     uint32_t hb = 0;
-                    const uint32_t granted = st_take(s_rq_ctl, 64u - (uint32_t)__popcll(bm0), hb);
+                    const uint32_t granted = st_take(s_rq_ctl, 64u - (uint32_t)__popcll(bm0), hb, rq_peek);
                     const bool take = !busy && (uint32_t)__popcll(~bm0 & below) < granted;
                     if (granted > 0) {
                         uint32_t e = 0;
@@ -458,7 +460,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
 #endif
         while (true) {
             ER_MARK("shader_loop_top");
-            const uint32_t avail = er_ring_load(&s_sq_ctl[ER_RING_COUNT]);
+            const unsigned long long sq_peek = er_ring_peek(s_sq_ctl);
+            const uint32_t avail = er_ring_peek_count(sq_peek);
             if (avail == 0) {
                 if (v_ctl[C_DONE]) break;
                 __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
             ER_MARK("shader_take");
             ER_TPS(0);
             uint32_t hb = 0;
-            const uint32_t granted = st_take(s_sq_ctl, 64u, hb);
+            const uint32_t granted = st_take(s_sq_ctl, 64u, hb, sq_peek);
             if (granted == 0) continue;          // another wave was quicker
             have = (uint32_t)lane < granted;
             if (have && !er_ring_get(s_sq, ST_SQ_LOG2, hb + (uint32_t)lane, e)) { have = false; atomicOr(status, ST_ERR_SHADE); }
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 // another slot has taken it)
                 const unsigned long long mw = __ballot(want_pixel);
                 uint32_t hb2 = 0;
-                const uint32_t granted2 = st_take(s_px_ctl, (uint32_t)__popcll(mw), hb2);
+                const uint32_t granted2 = st_take(s_px_ctl, (uint32_t)__popcll(mw), hb2, er_ring_peek(s_px_ctl));
                 const uint32_t rank = (uint32_t)__popcll(mw & below);
                 if (want_pixel && rank < granted2) {
                     const uint32_t ppos = hb2 + rank, pcell = ppos & (ring_cap - 1u);

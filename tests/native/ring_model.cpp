@@ -46,9 +46,9 @@ struct Pixel {
 
 struct Ring {
     std::vector<uint32_t> cells;
-    uint32_t ctl[ER_RING_WORDS] = {0, 0, 0};
+    alignas(8) uint32_t ctl[ER_RING_WORDS] = {0, 0, 0, 0};
     uint32_t log2 = 0;
-    void init(uint32_t l2) { log2 = l2; cells.assign(1u << l2, 0u); ctl[0] = ctl[1] = ctl[2] = 0; }
+    void init(uint32_t l2) { log2 = l2; cells.assign(1u << l2, 0u); ctl[0] = ctl[1] = ctl[2] = ctl[3] = 0; }
 };
 
 struct Model {
@@ -269,7 +269,7 @@ struct Model {
             if (!getenv("ER_MODEL_DEBUG")) return;
             while (!stop.load()) {
                 std::this_thread::sleep_for(std::chrono::seconds(1));
-                auto d = [&](const char* n, Ring& r) { fprintf(stderr, " %s t%u c%u h%u", n, er_ring_load(&r.ctl[0]), er_ring_load(&r.ctl[1]), er_ring_load(&r.ctl[2])); };
+                auto d = [&](const char* n, Ring& r) { fprintf(stderr, " %s t%u c%u h%u", n, er_ring_load(&r.ctl[ER_RING_TAIL]), er_ring_load(&r.ctl[ER_RING_COUNT]), er_ring_load(&r.ctl[ER_RING_HEAD])); };
                 d("rq", rq); d("sq", sq); d("px", px);
                 fprintf(stderr, " live %u done %u\n", er_ring_load(&live), er_ring_load(&done));
             }
