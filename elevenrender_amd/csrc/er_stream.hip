@@ -337,7 +337,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
             uint2* stack = s_stack + (size_t)wave * (WF_LDS_STACK * 64) + lane;
             Trav T;
             trav_begin(T, f3s(0), f3(0, 0, 1), false, -1, 0.0f);
-            bool busy = false;
+            bool busy = false, done = false, done_occl = false;      // a ray in traversal / a finished ray whose result is not yet published
 #if ER_TRACER_PRIO
             __builtin_amdgcn_s_setprio(ER_TRACER_PRIO);
 #endif
@@ -345,11 +345,29 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
             uint32_t idle = 0, progress = 0;
             while (true) {
                 ER_MARK("tracer_loop_top");
-                // idle lanes take rays from the ring; skipped while fewer than refill_min lanes are idle (it costs the whole wave ~40
-                // instructions and, when rays are taken, a pair of dependent loads) or the ring has nothing published
+                // Every refill_min idle lanes the wave does its ring work in one go: FIRST the finished rays of the idle lanes are
+                // published (results out, then the slot's in-flight count; the tracer that takes it to zero hands the slot to the
+                // shaders), THEN the idle lanes take rays from the ring.  Between two such visits a finished lane just sits idle with
+                // its result in registers: publishing per iteration cost the whole wave ~200 instructions on 86 % of its iterations
+                // (some lane of 64 nearly always finishes), for the two or three lanes concerned.
                 const unsigned long long bm0 = __ballot(busy);
                 unsigned long long rq_peek = 0;
-                if ((64u - (unsigned)__popcll(bm0) >= refill_min || bm0 == 0) && er_ring_peek_count(rq_peek = er_ring_peek(s_rq_ctl)) > 0) {
+                const bool visit = 64u - (unsigned)__popcll(bm0) >= refill_min || bm0 == 0;
+                if (visit && __ballot(done)) {
+                    ER_MARK("tracer_publish");
+                    if (done) st_write_result(W, rec, T.shadow, done_occl, T.overflow, T.s0, T.s1);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    bool last = false;
+                    uint32_t old = 0;
+                    if (done) {
+                        old = atomicSub(&s_wait[ls], 1u);
+                        last = (old & 0xFFu) == 1u;
+                    }
+                    st_push<ST_SQ_LOG2>(s_sq, s_sq_ctl, last, ls | ((old & ST_FIN) ? (1u << ST_SLOT_BITS) : 0u), status, ST_ERR_SHADE);
+                    done = false;
+                    ER_MARK("tracer_publish_end");
+                }
+                if (visit && er_ring_peek_count(rq_peek = er_ring_peek(s_rq_ctl)) > 0) {
                     uint32_t hb = 0;
                     const uint32_t granted = st_take(s_rq_ctl, 64u - (uint32_t)__popcll(bm0), hb, rq_peek);
                     const bool take = !busy && (uint32_t)__popcll(~bm0 & below) < granted;
@@ -419,22 +437,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 bool occl = false;
                 if (busy) {
                     if (do_step && trav_apply<COUNT>(T, S, st, D, c_nodes, c_tris)) { occl = true; finished = true; }
-                    if (finished) {
-                        st_write_result(W, rec, T.shadow, occl, T.overflow, T.s0, T.s1);
-                        busy = false;
-                    }
-                }
-                ER_MARK("tracer_publish");
-                // results out, then the slot's in-flight count; the tracer that takes it to zero hands the slot to the shaders
-                if (__ballot(finished)) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    bool last = false;
-                    uint32_t old = 0;
-                    if (finished) {
-                        old = atomicSub(&s_wait[ls], 1u);
-                        last = (old & 0xFFu) == 1u;
-                    }
-                    st_push<ST_SQ_LOG2>(s_sq, s_sq_ctl, last, ls | ((old & ST_FIN) ? (1u << ST_SLOT_BITS) : 0u), status, ST_ERR_SHADE);
+                    if (finished) { busy = false; done = true; done_occl = occl; }
                 }
 #ifdef ER_TIME_PROBE
                 if (lane == 0) atomicAdd(&s_tp[12], (unsigned)((__builtin_amdgcn_s_memtime() - tr0) >> 4));

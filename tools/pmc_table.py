@@ -72,6 +72,22 @@ def main():
         if g("tcp_stall", c) is not None and ga:
             # GRBM_GUI_ACTIVE sums the 8 XCDs; the TCP counters sum the 256 CUs
             ratio(f"{c} per CU / kernel cycles", g("tcp_stall", c) / 256.0, ga / 8.0)
+    # vector-memory front end (tools/pmc_ta.sh): *_sum counters add the 256 CUs, GRBM_GUI_ACTIVE adds the 8 XCDs
+    def per_cu_cycle(p, c):
+        return (g(p, c) / 256.0, (g(p, "GRBM_GUI_ACTIVE") or 0) / 8.0) if g(p, c) is not None else (None, None)
+    for label, p, c in (("TA busy   (TA_TA_BUSY per CU / kernel cycles)", "ta1", "TA_TA_BUSY_sum"),
+                        ("TA address stalled by the TCP / kernel cycles", "ta2", "TA_ADDR_STALLED_BY_TC_CYCLES_sum"),
+                        ("TA data stalled by the TCP / kernel cycles", "ta2", "TA_DATA_STALLED_BY_TC_CYCLES_sum"),
+                        ("vector-memory wave-instructions per CU per cycle", "ta1", "TA_TOTAL_WAVEFRONTS_sum"),
+                        ("TCP 64-byte cache accesses per CU per cycle", "tcp2", "TCP_TOTAL_CACHE_ACCESSES_sum"),
+                        ("TCP lane accesses per CU per cycle", "tcp4", "TCP_TOTAL_ACCESSES_sum"),
+                        ("TCP -> L2 read requests per CU per cycle", "tcp2", "TCP_TCC_READ_REQ_sum")):
+        a, b = per_cu_cycle(p, c)
+        ratio(label, a, b)
+    ratio("TA busy cycles per vector-memory wave-instruction", g("ta1", "TA_TA_BUSY_sum"), g("ta1", "TA_TOTAL_WAVEFRONTS_sum"), fmt="{:.1f}")
+    ratio("L1 miss share   (TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES)", g("tcp2", "TCP_TCC_READ_REQ_sum"), g("tcp2", "TCP_TOTAL_CACHE_ACCESSES_sum"))
+    ratio("L2 read latency seen by the TCP, cycles   (TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ)", g("tcp3", "TCP_TCC_READ_REQ_LATENCY_sum"), g("tcp2", "TCP_TCC_READ_REQ_sum"), fmt="{:.0f}")
+    ratio("time of a wave-instruction in the TCP, cycles   (TCP_TCP_LATENCY / TCP_TA_TCP_STATE_READ)", g("tcp3", "TCP_TCP_LATENCY_sum"), g("tcp3", "TCP_TA_TCP_STATE_READ_sum"), fmt="{:.0f}")
     ratio("LDS bank-conflict cycles / LDS active cycles", g("lds", "SQ_LDS_BANK_CONFLICT"), g("lds", "SQ_LDS_IDX_ACTIVE"))
     f, w = g("fetch", "FETCH_SIZE"), g("write", "WRITE_SIZE")
     if f is not None and w is not None:
