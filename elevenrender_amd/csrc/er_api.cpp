@@ -286,7 +286,6 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
             cus = std::max(1, cus);
             if (px < 150000u) sched = ER_FLAG_FUSED;
-            else if (px > 4000000u && s->tri_count > 4000000u) sched = ER_FLAG_WAVEFRONT;
             else if (((owned.size() + (size_t)cus - 1) / (size_t)cus + 4u) * 64u > ER_STREAM_MAX_RING) sched = ER_FLAG_WAVEFRONT;     // (beyond the streaming schedule's pixel rings)
             else sched = ER_FLAG_STREAM;
         }
