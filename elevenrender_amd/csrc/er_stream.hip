@@ -256,13 +256,14 @@ __device__ __forceinline__ void st_write_result(const StState& W, uint32_t rec, 
 
 template <bool COUNT, bool EXT>
 __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StState W, const uint32_t* deal, uint32_t deal_count, uint2* ring_base, uint32_t ring_cap,
-                                                          uint32_t* status, uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min) {
+                                                          uint32_t* status, uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min, uint32_t fin_min) {
     constexpr uint32_t RQ_LOG2 = ST_RQ_LOG2, SLOTS = ER_STREAM_SLOTS, TOP_NODES = ER_STREAM_TOP_NODES;
     __shared__ uint32_t s_rq[1u << RQ_LOG2];
     __shared__ uint32_t s_sq[1u << ST_SQ_LOG2];
+    __shared__ uint32_t s_fq[1u << ST_SQ_LOG2];      // finish ring: slots whose path is over and whose sample waits to be accumulated
     __shared__ uint32_t s_wait[SLOTS];
     __shared__ uint32_t s_pxbits[ST_PXBITS_WORDS];
-    __shared__ __attribute__((aligned(8))) uint32_t s_rq_ctl[ER_RING_WORDS], s_sq_ctl[ER_RING_WORDS], s_px_ctl[ER_RING_WORDS];
+    __shared__ __attribute__((aligned(8))) uint32_t s_rq_ctl[ER_RING_WORDS], s_sq_ctl[ER_RING_WORDS], s_px_ctl[ER_RING_WORDS], s_fq_ctl[ER_RING_WORDS];
     __shared__ uint32_t s_ctl[C_WORDS];
     __shared__ float4 s_top[TOP_NODES * ER_NODE8_PIECES];
 #ifdef ER_TIME_PROBE
@@ -279,9 +280,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
 
     // ---- start: empty rings (every cell = lap 0, empty), then every slot takes a pixel and queues its first camera ray ----
     for (uint32_t i = threadIdx.x; i < (1u << RQ_LOG2); i += ST_THREADS) s_rq[i] = 0;
-    for (uint32_t i = threadIdx.x; i < (1u << ST_SQ_LOG2); i += ST_THREADS) s_sq[i] = 0;
+    for (uint32_t i = threadIdx.x; i < (1u << ST_SQ_LOG2); i += ST_THREADS) { s_sq[i] = 0; s_fq[i] = 0; }
     for (uint32_t i = threadIdx.x; i < ST_PXBITS_WORDS; i += ST_THREADS) s_pxbits[i] = 0;
-    if (threadIdx.x < ER_RING_WORDS) { s_rq_ctl[threadIdx.x] = 0; s_sq_ctl[threadIdx.x] = 0; s_px_ctl[threadIdx.x] = 0; }
+    if (threadIdx.x < ER_RING_WORDS) { s_rq_ctl[threadIdx.x] = 0; s_sq_ctl[threadIdx.x] = 0; s_px_ctl[threadIdx.x] = 0; s_fq_ctl[threadIdx.x] = 0; }
     if (threadIdx.x < C_WORDS) s_ctl[threadIdx.x] = 0;
     __syncthreads();
     // this workgroup's pixels in the order of its tiles: the first SLOTS valid ones start in the slots, the others
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 if (bm == 0) {
                     if (v_ctl[C_DONE]) break;
                     __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
-                    const uint32_t pr = er_ring_load(&s_rq_ctl[ER_RING_TAIL]) + er_ring_load(&s_sq_ctl[ER_RING_TAIL]);
+                    const uint32_t pr = er_ring_load(&s_rq_ctl[ER_RING_TAIL]) + er_ring_load(&s_sq_ctl[ER_RING_TAIL]) + er_ring_load(&s_fq_ctl[ER_RING_TAIL]);
                     if (pr != progress) { progress = pr; idle = 0; }
                     if (++idle > ST_WATCHDOG) {
                         if (lane == 0) { atomicOr(status, 1u); s_ctl[C_DONE] = 1; }
@@ -463,12 +464,12 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
 #endif
         while (true) {
             ER_MARK("shader_loop_top");
-            const unsigned long long sq_peek = er_ring_peek(s_sq_ctl);
-            const uint32_t avail = er_ring_peek_count(sq_peek);
-            if (avail == 0) {
+            const unsigned long long sq_peek = er_ring_peek(s_sq_ctl), fq_peek = er_ring_peek(s_fq_ctl);
+            const uint32_t avail = er_ring_peek_count(sq_peek), favail = er_ring_peek_count(fq_peek);
+            if (avail == 0 && favail == 0) {
                 if (v_ctl[C_DONE]) break;
                 __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
-                const uint32_t pr = er_ring_load(&s_rq_ctl[ER_RING_TAIL]) + er_ring_load(&s_sq_ctl[ER_RING_TAIL]);
+                const uint32_t pr = er_ring_load(&s_rq_ctl[ER_RING_TAIL]) + er_ring_load(&s_sq_ctl[ER_RING_TAIL]) + er_ring_load(&s_fq_ctl[ER_RING_TAIL]);
                 if (pr != progress) { progress = pr; idle = 0; }
                 if (++idle > ST_WATCHDOG) {
                     if (lane == 0) { atomicOr(status, 2u); s_ctl[C_DONE] = 1; }
@@ -477,30 +478,39 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 continue;
             }
             idle = 0;
-            if (avail < batch_min && spins < 24u) {     // a fuller batch costs the same instructions: wait a little for one
-                spins++;
-                __builtin_amdgcn_s_sleep(ST_BATCH_SLEEP);
-                continue;
+            // Two kinds of step.  A SHADING step runs the bounce for a batch of slots whose rays are traced; a slot whose path ends
+            // there is not finished on the spot but handed to the finish ring.  A FINISHING step accumulates the samples of a batch of
+            // such slots, puts their pixels back and starts the next samples.  One path in 4.5 steps ends, so finishing inline ran
+            // the ~1 400 instructions of accumulate + pixel ring + camera ray in nearly every shading step for a fifth of its lanes;
+            // as batches of its own it runs full.  A full finish batch goes first (its slots hold no ray in flight); a partial one
+            // runs when the shade ring has too little for a batch.
+            bool fin_mode = favail >= fin_min;
+            if (!fin_mode && avail < batch_min) {
+                if (favail > 0 && (avail == 0 || spins >= 8u)) fin_mode = true;
+                else if (spins < 24u) {     // a fuller batch costs the same instructions: wait a little for one
+                    spins++;
+                    __builtin_amdgcn_s_sleep(ST_BATCH_SLEEP);
+                    continue;
+                }
             }
             spins = 0;
             ER_MARK("shader_take");
             ER_TPS(0);
             uint32_t hb = 0;
-            const uint32_t granted = st_take(s_sq_ctl, 64u, hb, sq_peek);
+            const uint32_t granted = fin_mode ? st_take(s_fq_ctl, 64u, hb, fq_peek) : st_take(s_sq_ctl, 64u, hb, sq_peek);
             if (granted == 0) continue;          // another wave was quicker
             have = (uint32_t)lane < granted;
-            if (have && !er_ring_get(s_sq, ST_SQ_LOG2, hb + (uint32_t)lane, e)) { have = false; atomicOr(status, ST_ERR_SHADE); }
+            if (have && !(fin_mode ? er_ring_get(s_fq, ST_SQ_LOG2, hb + (uint32_t)lane, e) : er_ring_get(s_sq, ST_SQ_LOG2, hb + (uint32_t)lane, e))) { have = false; atomicOr(status, ST_ERR_SHADE); }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             bool push_closest = false, push_shadow = false, push_light = false, retire = false;
             const uint32_t ls = e & ST_SLOT_MASK;
             const uint32_t slot = g0 + ls;
-            bool want_pixel = false;
+            bool want_pixel = false, to_finish = false;
             uint32_t rs = 0, left_after = 0, done_idx = 0;
             ER_MARK("shader_step");
             ER_TPS(1);
-            if (have) {
+            if (have && !fin_mode) {
                 const bool fin_only = (e >> ST_SLOT_BITS) != 0;
-                uint32_t idx = W.pix(slot);
                 float4 L4 = W.light(slot), R4 = W.reduc(slot);
                 F3 light = f3(L4.x, L4.y, L4.z), reduction = f3(R4.x, R4.y, R4.z);
                 rs = __builtin_bit_cast(uint32_t, L4.w);
@@ -571,18 +581,10 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 if (done && (pending || lpending)) {
                     fin_next = true;          // the path is over but a shadow query is in flight: come back once, without a ray
                 } else if (done) {
-                    // src/kernel.cpp:597-645
-                    float4 an = W.aov_n(slot), at = W.aov_t(slot), ab = W.aov_b(slot);
-                    const uint32_t sa = S.samples[idx];
-                    const uint32_t sa2 = accumulate_sample(S, idx, sa, light, f3(an.x, an.y, an.z), f3(at.x, at.y, at.z), f3(ab.x, ab.y, ab.z));
-                    if (sa2 != sa) S.samples[idx] = sa2;
-                    S.rng[idx] = rs;
-                    c_paths++;
-                    // the sample is done: the pixel goes back to the ring (below, as a wave) and the slot takes the next one
-                    left_after = W.left(slot) - 1;
-                    done_idx = idx;
+                    // the path is over and nothing is pending: its sample goes to the finish ring (light and RNG state through the record)
+                    W.light(slot) = make_float4(light.x, light.y, light.z, __builtin_bit_cast(float, rs));
                     alive = false;
-                    want_pixel = true;
+                    to_finish = true;
                 } else {
                     push_closest = true;
                 }
@@ -598,6 +600,27 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                                                 __builtin_bit_cast(float, bounce | (pending ? WF_PENDING_BIT : 0u) | ((EXT && lpending) ? WF_LPENDING_BIT : 0u)));
                     s_wait[ls] = (push_closest ? 1u : 0u) + (push_shadow ? 1u : 0u) + (push_light ? 1u : 0u) + (fin_next ? ST_FIN : 0u);
                 }
+            }
+            if (!fin_mode) {
+                if (__ballot(to_finish)) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the record first, then the entry
+                    st_push<ST_SQ_LOG2>(s_fq, s_fq_ctl, to_finish, ls, status, ST_ERR_SHADE);
+                }
+            } else if (have) {
+                // src/kernel.cpp:597-645
+                const uint32_t idx = W.pix(slot);
+                const float4 L4 = W.light(slot);
+                const float4 an = W.aov_n(slot), at = W.aov_t(slot), ab = W.aov_b(slot);
+                rs = __builtin_bit_cast(uint32_t, L4.w);
+                const uint32_t sa = S.samples[idx];
+                const uint32_t sa2 = accumulate_sample(S, idx, sa, f3(L4.x, L4.y, L4.z), f3(an.x, an.y, an.z), f3(at.x, at.y, at.z), f3(ab.x, ab.y, ab.z));
+                if (sa2 != sa) S.samples[idx] = sa2;
+                S.rng[idx] = rs;
+                c_paths++;
+                // the sample is done: the pixel goes back to the ring (below, as a wave) and the slot takes the next one
+                left_after = W.left(slot) - 1;
+                done_idx = idx;
+                want_pixel = true;
             }
             ER_MARK("shader_pixel_ring");
             ER_TPS(7);
@@ -773,6 +796,11 @@ void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lig
         int v = e ? atoi(e) : 64;      // (five shader waves: a step that is not full is capacity lost)
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
+    static const uint32_t fin_min = [] {
+        const char* e = getenv("ER_STREAM_FIN_MIN");
+        int v = e ? atoi(e) : 64;      // (a finishing step runs as soon as it is full)
+        return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+    }();
     if (S.owned_tile_count == 0 || n_samples == 0) return;
     const bool ext = er_ext_active(S);
     auto k = count ? (ext ? er_stream_kernel<true, true> : er_stream_kernel<true, false>) : (ext ? er_stream_kernel<false, true> : er_stream_kernel<false, false>);
@@ -781,7 +809,7 @@ void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lig
     st.spill = (uint2*)spill;
     st.slots = slots;
     st.stride = er_stream_record_bytes(lights);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(ST_THREADS), 0, stream, S, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min);
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(ST_THREADS), 0, stream, S, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
 }
 
 uint32_t er_stream_record_bytes(bool lights) { return lights ? ST_STRIDE_LIGHTS : ST_STRIDE_PLAIN; }

@@ -1,5 +1,5 @@
 // ring_model.cpp -- host-thread model of ONE workgroup of the streaming schedule (csrc/er_stream.hip), built on the very ring
-// functions the kernel uses (csrc/er_ring.h compiled with -DER_RING_HOST_MODEL): ray ring, shade ring and the pixel ring with its
+// functions the kernel uses (csrc/er_ring.h compiled with -DER_RING_HOST_MODEL): ray ring, shade ring, finish ring and the pixel ring with its
 // "entry read" bits, all with SMALL capacities so that every ring wraps hundreds of times in a run, with the per-slot in-flight counters and the slot / pixel hand-offs
 // in between.  "Waves" are threads of LANES lanes; what a wave does with one reservation (reserve n, put n cells, publish n;
 // grant n, get n cells) is done in that order by its thread.  Slot records and per-pixel state are PLAIN memory, as on
@@ -38,6 +38,7 @@ struct Slot {              // plain memory: one slot record (HBM on the device)
     uint32_t result[3] = {0, 0, 0};     // written by tracers: 1 + hash(ray identity)
     uint32_t pushed[3] = {0, 0, 0};     // ray identities the shader pushed for this step (0 = none)
     bool fin_next = false;
+    uint32_t light = 0;                 // written by the shading step that ends the path, read by the finishing step (plain: the finish ring orders them)
 };
 struct Pixel {
     uint32_t done = 0;                  // plain: only the holder touches it
@@ -56,7 +57,7 @@ struct Model {
     std::vector<Slot> slots;
     std::vector<Pixel> pixels;
     std::vector<uint32_t> s_wait;
-    Ring rq, sq, px;       // px: only ctl is used as a ring; its cells are px_cells + px_bits
+    Ring rq, sq, fq, px;   // px: only ctl is used as a ring; its cells are px_cells + px_bits
     std::vector<uint64_t> px_cells;
     std::vector<uint32_t> px_bits;
     uint32_t px_cap = 0;
@@ -121,7 +122,7 @@ struct Model {
             if (g == 0) {
                 if (er_ring_load(&done)) break;
                 std::this_thread::yield();
-                const uint32_t pr = er_ring_load(&rq.ctl[ER_RING_TAIL]) + er_ring_load(&sq.ctl[ER_RING_TAIL]);
+                const uint32_t pr = er_ring_load(&rq.ctl[ER_RING_TAIL]) + er_ring_load(&sq.ctl[ER_RING_TAIL]) + er_ring_load(&fq.ctl[ER_RING_TAIL]);
                 if (pr != progress) { progress = pr; idle = 0; }
                 if (++idle > 40000000u) { err("tracer watchdog"); er_ring_store(&done, 1u); break; }
                 continue;
@@ -141,12 +142,16 @@ struct Model {
     void shader() {
         uint32_t progress = 0, idle = 0;
         while (true) {
+            // a full finishing batch first, else a shading batch, else whatever the finish ring holds (er_stream.hip's shader loop)
             uint32_t e[LANES];
-            const int g = take(sq, LANES, e);
+            bool fin_mode = er_ring_peek_count(er_ring_peek(fq.ctl)) >= (uint32_t)LANES;
+            int g = fin_mode ? take(fq, LANES, e) : 0;
+            if (g == 0) { fin_mode = false; g = take(sq, LANES, e); }
+            if (g == 0) { fin_mode = true; g = take(fq, LANES, e); }
             if (g == 0) {
                 if (er_ring_load(&done)) break;
                 std::this_thread::yield();
-                const uint32_t pr = er_ring_load(&rq.ctl[ER_RING_TAIL]) + er_ring_load(&sq.ctl[ER_RING_TAIL]);
+                const uint32_t pr = er_ring_load(&rq.ctl[ER_RING_TAIL]) + er_ring_load(&sq.ctl[ER_RING_TAIL]) + er_ring_load(&fq.ctl[ER_RING_TAIL]);
                 if (pr != progress) { progress = pr; idle = 0; }
                 if (++idle > 40000000u) { err("shader watchdog"); er_ring_store(&done, 1u); break; }
                 continue;
@@ -156,7 +161,23 @@ struct Model {
             int n_rays = 0;
             uint32_t want_px[LANES], back_px[LANES], back_left[LANES];
             int n_want = 0, n_back = 0;
-            for (int i = 0; i < g; i++) {
+            uint32_t fin[LANES];
+            int n_fin = 0;
+            for (int i = 0; i < g && fin_mode; i++) {
+                // FINISHING step: the sample is accumulated, the pixel goes back, the slot takes the next one
+                const uint32_t s = e[i];
+                if (s >= n_slots) { err("garbage finish-ring entry"); continue; }
+                Slot& S = slots[s];
+                if (S.light != 1u + hash32(S.pixel * 53u + S.sample * 19u)) err("a sample was finished before its path was over");
+                S.light = 0;
+                Pixel& P = pixels[S.pixel];
+                if (P.done != S.sample) err("a pixel's samples ran out of order");
+                P.done++;
+                P.holders.fetch_sub(1);
+                if (S.left - 1 > 0) { back_px[n_back] = S.pixel; back_left[n_back] = S.left - 1; n_back++; }
+                want_px[n_want++] = s;
+            }
+            for (int i = 0; i < g && !fin_mode; i++) {
                 const uint32_t s = e[i] & ((1u << SLOT_BITS) - 1u);
                 const bool fin_only = (e[i] >> SLOT_BITS) != 0;
                 if (s >= n_slots) { err("garbage shade-ring entry"); continue; }
@@ -179,13 +200,10 @@ struct Model {
                 if (donep && (pend_shadow || pend_light)) {
                     S.fin_next = true;
                 } else if (donep) {
-                    Pixel& P = pixels[S.pixel];
-                    if (P.done != S.sample) err("a pixel's samples ran out of order");
-                    P.done++;
-                    P.holders.fetch_sub(1);
+                    // the path is over, nothing pending: the sample goes to the finish ring, its light through the slot record
                     S.fin_next = false;
-                    if (S.left - 1 > 0) { back_px[n_back] = S.pixel; back_left[n_back] = S.left - 1; n_back++; }
-                    want_px[n_want++] = s;
+                    S.light = 1u + hash32(S.pixel * 53u + S.sample * 19u);
+                    fin[n_fin++] = s;
                     continue;
                 }
                 uint32_t n = 0;
@@ -194,6 +212,7 @@ struct Model {
                 if (pend_light) { S.pushed[2] = 3u + hash32(S.pixel * 41u + S.sample * 17u + S.bounce * 3001u); rays[n_rays++] = s | (2u << SLOT_BITS); n++; }
                 er_ring_store(&s_wait[s], n + (S.fin_next ? FIN : 0u));
             }
+            push(fq, fin, n_fin, variant != 2);
             // finished samples: pixels back to the ring (cell behind its "entry read" bit), then as many taken as there are
             uint32_t retire = 0;
             if (n_want) {
@@ -240,7 +259,7 @@ struct Model {
         s_wait.assign(n_slots, 0u);
         uint32_t sq_log2 = 0;
         while ((1u << sq_log2) < n_slots) sq_log2++;
-        rq.init(rq_log2); sq.init(sq_log2);
+        rq.init(rq_log2); sq.init(sq_log2); fq.init(sq_log2);
         px_cap = 1;
         while (px_cap < n_pixels) px_cap <<= 1;
         px_cells.assign(px_cap, 0);
@@ -270,7 +289,7 @@ struct Model {
             while (!stop.load()) {
                 std::this_thread::sleep_for(std::chrono::seconds(1));
                 auto d = [&](const char* n, Ring& r) { fprintf(stderr, " %s t%u c%u h%u", n, er_ring_load(&r.ctl[ER_RING_TAIL]), er_ring_load(&r.ctl[ER_RING_COUNT]), er_ring_load(&r.ctl[ER_RING_HEAD])); };
-                d("rq", rq); d("sq", sq); d("px", px);
+                d("rq", rq); d("sq", sq); d("fq", fq); d("px", px);
                 fprintf(stderr, " live %u done %u\n", er_ring_load(&live), er_ring_load(&done));
             }
         });
@@ -296,7 +315,7 @@ struct Model {
         };
         uint32_t bad = 0;
         if (variant != 2) {
-            bad += ring_clean(rq, "ray ring", 0) + ring_clean(sq, "shade ring", 0);
+            bad += ring_clean(rq, "ray ring", 0) + ring_clean(sq, "shade ring", 0) + ring_clean(fq, "finish ring", 0);
             for (uint32_t w : px_bits) if (w) bad++;
         }
         if (px.ctl[ER_RING_COUNT] != 0) bad++;
