@@ -607,6 +607,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                     st_push<ST_SQ_LOG2>(s_fq, s_fq_ctl, to_finish, ls, status, ST_ERR_SHADE);
                 }
             } else if (have) {
+                ER_TPS(6);
                 // src/kernel.cpp:597-645
                 const uint32_t idx = W.pix(slot);
                 const float4 L4 = W.light(slot);
