@@ -306,8 +306,8 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         s->stream_blocks = (uint32_t)prop.multiProcessorCount;
-        s->stream_tracers = 11;      // 11 tracer + 5 shader waves (shader waves at issue priority 1, er_stream.hip); round 2: 10 + 6
-        if (const char* e = getenv("ER_STREAM_TRACERS")) s->stream_tracers = (uint32_t)std::min(12, std::max(1, atoi(e)));   // tuning knob
+        s->stream_tracers = 12;      // 12 tracer + 4 shader waves (shader waves at issue priority 1; finished and escaped paths handled in batches of their own, er_stream.hip); before: 11 + 5, round 2: 10 + 6
+        if (const char* e = getenv("ER_STREAM_TRACERS")) s->stream_tracers = (uint32_t)std::min(13, std::max(1, atoi(e)));   // tuning knob
         const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
         if ((rc = upload(s->d_wf4, nullptr, slots * er_stream_record_bytes(lights_on) / sizeof(float4), s->stream)) != ER_OK) return rc;
         if ((rc = upload(s->d_wf1, nullptr, 2, s->stream)) != ER_OK) return rc;        // [1] status word

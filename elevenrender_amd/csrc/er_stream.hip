@@ -68,6 +68,10 @@ static_assert(ER_STREAM_SLOTS <= (1u << ST_SLOT_BITS) && ST_SLOT_BITS + 2 <= ER_
 // ray-ring entry = local slot | kind << 11: 0 closest hit, 1 HDRI shadow query, 2 point-light query;
 // shade-ring entry = local slot | fin << 11 (fin: the slot is only finalised, ER_WF_FINALIZE_ONLY)
 #define ST_FIN 0x100u            // the same flag in s_wait
+// flags the TRACERS add to a slot's s_wait word while its rays finish (the tracer that takes the count to zero sees them all):
+#define ST_ESC 0x200u            //   the closest-hit ray found no candidate at all: the path has left the scene
+#define ST_AMB1 0x400u           //   the HDRI shadow query ended ambiguous (the shader must resolve it by exact distances)
+#define ST_AMB2 0x800u           //   ... the point-light query
 // ring capacities (log2).  With the checked cells a full ring only makes its producers wait (shader waves for the tracers
 // to drain the ray ring -- which they do whatever the shaders are doing -- never the other way round: the shade ring holds
 // a slot at most once, so ER_STREAM_SLOTS cells can never be full), so capacities are a tuning matter, not a safety margin.
@@ -98,7 +102,7 @@ static_assert((1u << ST_RQ_LOG2) >= ER_STREAM_SLOTS && (1u << ST_RQ_LOG2) >= 4u 
 #ifndef ER_STREAM_TOP_NODES
 #define ER_STREAM_TOP_NODES 585
 #endif
-#define ST_MAX_TRACERS 12
+#define ST_MAX_TRACERS 13
 enum { C_LIVE = 0, C_DONE, C_INIT, C_WORDS };
 #ifndef ST_IDLE_SLEEP
 #define ST_IDLE_SLEEP 16         // s_sleep argument (x 64 cycles) of a wave that found nothing to do (4 .. 48 measured: no difference)
@@ -359,12 +363,20 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                     if (done) st_write_result(W, rec, T.shadow, done_occl, T.overflow, T.s0, T.s1);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     bool last = false;
-                    uint32_t old = 0;
+                    uint32_t fin = 0;
                     if (done) {
-                        old = atomicSub(&s_wait[ls], 1u);
-                        last = (old & 0xFFu) == 1u;
+                        const bool esc = !T.shadow && !T.overflow && T.s0 < 0 && T.s1 < 0;
+                        const bool amb = T.shadow && !done_occl && (T.overflow || T.s0 >= 0);       // (st_write_result's verdicts 2 and 3)
+                        const uint32_t add = (esc ? ST_ESC : 0u) + (amb ? (kind == 1u ? ST_AMB1 : ST_AMB2) : 0u) - 1u;
+                        fin = atomicAdd(&s_wait[ls], add) + add;
+                        last = (fin & 0xFFu) == 0u;
                     }
-                    st_push<ST_SQ_LOG2>(s_sq, s_sq_ctl, last, ls | ((old & ST_FIN) ? (1u << ST_SLOT_BITS) : 0u), status, ST_ERR_SHADE);
+                    // A slot whose path has just left the scene, with every pending shadow verdict certain, has nothing for a shading step
+                    // to do but look up the sky: it goes straight to the finish ring (flagged), which does that for full batches of such
+                    // slots.  Everything else goes to the shade ring.
+                    const bool escaped = last && (fin & ST_ESC) != 0u && (fin & (ST_AMB1 | ST_AMB2)) == 0u;
+                    st_push<ST_SQ_LOG2>(s_sq, s_sq_ctl, last && !escaped, ls | ((fin & ST_FIN) ? (1u << ST_SLOT_BITS) : 0u), status, ST_ERR_SHADE);
+                    st_push<ST_SQ_LOG2>(s_fq, s_fq_ctl, escaped, ls | (1u << ST_SLOT_BITS), status, ST_ERR_SHADE);
                     done = false;
                     ER_MARK("tracer_publish_end");
                 }
@@ -608,13 +620,48 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 }
             } else if (have) {
                 ER_TPS(6);
-                // src/kernel.cpp:597-645
                 const uint32_t idx = W.pix(slot);
                 const float4 L4 = W.light(slot);
-                const float4 an = W.aov_n(slot), at = W.aov_t(slot), ab = W.aov_b(slot);
+                F3 light = f3(L4.x, L4.y, L4.z);
                 rs = __builtin_bit_cast(uint32_t, L4.w);
+                if ((e >> ST_SLOT_BITS) != 0) {
+                    // straight from the tracers: the path's last ray left the scene.  What the shading step does for such a slot --
+                    // the previous bounce's shadow verdicts (certain ones: the tracers checked), then the miss branch of the bounce.
+                    const float4 R4 = W.reduc(slot);
+                    F3 reduction = f3(R4.x, R4.y, R4.z);
+                    const uint32_t packed = __builtin_bit_cast(uint32_t, R4.w);
+                    uint32_t bounce = packed & 0xFFFFu;
+                    if (packed & WF_PENDING_BIT) {
+                        const float4 c = W.occluded(slot) ? W.c_occ(slot) : W.c_vis(slot);
+                        light = light + f3(c.x, c.y, c.z);
+                    }
+                    if (EXT && (packed & WF_LPENDING_BIT)) {
+                        const uint32_t q = slot + W.slots;
+                        const float4 c = W.occluded(q) ? W.c_occ(q) : W.c_vis(q);
+                        light = light + f3(c.x, c.y, c.z);
+                    }
+                    const float4 d = W.ray_d(slot);
+                    Ray ray;
+                    ray.o = f3s(0);
+                    ray.d = f3(d.x, d.y, d.z);
+                    float prev_pdf = EXT ? d.w : -1.0f;
+                    const int hslot = -1;
+                    bool done = false, pending = false, lpending = false;
+                    c_bounce++;
+// (the hooks belong to the hit branch, which `hslot = -1` compiles out)
+#define ER_BOUNCE_HDRI_QUERY(sr, self_slot, d_self, cv, co) ((void)(sr), (void)(self_slot), (void)(d_self), (void)(cv), (void)(co))
+#define ER_BOUNCE_LIGHT_QUERY(lr, limit, lv, lo) ((void)(lr), (void)(limit), (void)(lv), (void)(lo))
+#define ER_BOUNCE_FIRST_HIT(n, t, b) ((void)(n), (void)(t), (void)(b))
+#include "er_bounce.inc"
+#undef ER_BOUNCE_HDRI_QUERY
+#undef ER_BOUNCE_LIGHT_QUERY
+#undef ER_BOUNCE_FIRST_HIT
+                    (void)bounce; (void)done; (void)pending; (void)lpending; (void)prev_pdf;
+                }
+                // src/kernel.cpp:597-645
+                const float4 an = W.aov_n(slot), at = W.aov_t(slot), ab = W.aov_b(slot);
                 const uint32_t sa = S.samples[idx];
-                const uint32_t sa2 = accumulate_sample(S, idx, sa, f3(L4.x, L4.y, L4.z), f3(an.x, an.y, an.z), f3(at.x, at.y, at.z), f3(ab.x, ab.y, ab.z));
+                const uint32_t sa2 = accumulate_sample(S, idx, sa, light, f3(an.x, an.y, an.z), f3(at.x, at.y, at.z), f3(ab.x, ab.y, ab.z));
                 if (sa2 != sa) S.samples[idx] = sa2;
                 S.rng[idx] = rs;
                 c_paths++;
@@ -803,6 +850,8 @@ void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lig
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
     if (S.owned_tile_count == 0 || n_samples == 0) return;
+    if (tracers > ST_MAX_TRACERS) tracers = ST_MAX_TRACERS;      // (the LDS traversal stacks are sized for that many; at least 3 shader waves stay)
+    if (tracers < 1u) tracers = 1u;
     const bool ext = er_ext_active(S);
     auto k = count ? (ext ? er_stream_kernel<true, true> : er_stream_kernel<true, false>) : (ext ? er_stream_kernel<false, true> : er_stream_kernel<false, false>);
     StState st;

@@ -30,6 +30,7 @@ namespace {
 constexpr int LANES = 4;            // lanes of a model wave
 constexpr uint32_t SLOT_BITS = 10;  // as ST_SLOT_BITS
 constexpr uint32_t FIN = 0x100u;    // as ST_FIN
+constexpr uint32_t ESC = 0x200u, AMB1 = 0x400u, AMB2 = 0x800u;   // as ST_ESC, ST_AMB1, ST_AMB2
 
 uint32_t hash32(uint32_t a) { a ^= a >> 16; a *= 0x7feb352dU; a ^= a >> 15; a *= 0x846ca68bU; a ^= a >> 16; return a; }
 
@@ -62,13 +63,16 @@ struct Model {
     std::vector<uint32_t> px_bits;
     uint32_t px_cap = 0;
     uint32_t live = 0, done = 0;
-    std::atomic<uint32_t> errors{0}, rays_traced{0}, rays_pushed{0};
+    std::atomic<uint32_t> errors{0}, rays_traced{0}, rays_pushed{0}, shortcuts{0};
 
     void err(const char* what) {
         if (errors.fetch_add(1) < 10) fprintf(stderr, "model error: %s\n", what);
     }
     static uint32_t lap_tag(uint32_t pos, uint32_t cap) { return ((((pos / cap) & 0x7Fu) + 1u) << 24); }
     uint32_t path_len(uint32_t pixel, uint32_t sample) const { return 1u + hash32(pixel * 977u + sample * 131u + 7u) % 5u; }
+    // does the path's last closest-hit ray leave the scene (else it ends at the bounce limit)?  is a shadow query's verdict ambiguous?
+    bool escapes(uint32_t pixel, uint32_t sample) const { return (hash32(pixel * 419u + sample * 61u + 3u) & 3u) != 0; }
+    bool ambiguous(uint32_t ident) const { return (hash32(ident ^ 0x5bd1e995u) & 7u) == 0; }
 
     // wave-level push of up to LANES payloads (one reservation)
     void push(Ring& r, const uint32_t* payload, int n, bool checked = true) {
@@ -103,15 +107,23 @@ struct Model {
     }
 
     // ---- what a tracer does when a ray is complete ----
-    void finish_ray(uint32_t s, uint32_t kind, uint32_t ident, uint32_t* sq_out, int& n_sq) {
+    void finish_ray(uint32_t s, uint32_t kind, uint32_t ident, uint32_t* sq_out, int& n_sq, uint32_t* fq_out, int& n_fq) {
         Slot& S = slots[s];
         if (S.pushed[kind] != ident) err("a tracer holds a ray its slot did not push");
         if (S.result[kind] != 0) err("a ray was traced twice");
         S.result[kind] = 1u + hash32(ident);
         rays_traced.fetch_add(1);
-        const uint32_t old = er_ring_add(&s_wait[s], (uint32_t)-1);
+        // the flags the kernel's tracers add with the decrement: the path's last ray escapes / a verdict is ambiguous
+        uint32_t add = (uint32_t)-1;
+        if (kind == 0 && S.bounce + 1 >= path_len(S.pixel, S.sample) && escapes(S.pixel, S.sample)) add += ESC;
+        if (kind != 0 && ambiguous(ident)) add += kind == 1 ? AMB1 : AMB2;
+        const uint32_t old = er_ring_add(&s_wait[s], add);
+        const uint32_t fin = old + add;
         if ((old & 0xFFu) == 0) err("in-flight counter below zero");
-        if ((old & 0xFFu) == 1u) sq_out[n_sq++] = s | ((old & FIN) ? (1u << SLOT_BITS) : 0u);
+        if ((fin & 0xFFu) == 0u) {
+            if ((fin & ESC) && !(fin & (AMB1 | AMB2))) fq_out[n_fq++] = s | (1u << SLOT_BITS);     // straight to the finish ring
+            else sq_out[n_sq++] = s | ((fin & FIN) ? (1u << SLOT_BITS) : 0u);
+        }
     }
 
     void first_tracer() {
@@ -128,14 +140,15 @@ struct Model {
                 continue;
             }
             idle = 0;
-            uint32_t out[LANES];
-            int n = 0;
+            uint32_t out[LANES], fout[LANES];
+            int n = 0, nf = 0;
             for (int i = 0; i < g; i++) {
                 const uint32_t s = e[i] & ((1u << SLOT_BITS) - 1u), kind = e[i] >> SLOT_BITS;
                 if (s >= n_slots || kind > 2) { err("garbage ray-ring entry"); continue; }
-                finish_ray(s, kind, slots[s].pushed[kind], out, n);
+                finish_ray(s, kind, slots[s].pushed[kind], out, n, fout, nf);
             }
             push(sq, out, n, variant != 2);
+            push(fq, fout, nf, variant != 2);
         }
     }
 
@@ -165,11 +178,26 @@ struct Model {
             int n_fin = 0;
             for (int i = 0; i < g && fin_mode; i++) {
                 // FINISHING step: the sample is accumulated, the pixel goes back, the slot takes the next one
-                const uint32_t s = e[i];
+                const uint32_t s = e[i] & ((1u << SLOT_BITS) - 1u);
+                const bool from_tracer = (e[i] >> SLOT_BITS) != 0;
                 if (s >= n_slots) { err("garbage finish-ring entry"); continue; }
                 Slot& S = slots[s];
-                if (S.light != 1u + hash32(S.pixel * 53u + S.sample * 19u)) err("a sample was finished before its path was over");
-                S.light = 0;
+                if (from_tracer) {
+                    shortcuts.fetch_add(1);
+                    // straight from the tracers: the last ray escaped and no verdict is ambiguous -- what the shading step checks and does
+                    if (S.fin_next) err("a finalise-only slot came through the tracers' finish entry");
+                    for (int k = 0; k < 3; k++) {
+                        if (S.pushed[k] && S.result[k] != 1u + hash32(S.pushed[k])) err("a slot was finished before its ray was traced");
+                        if (!S.pushed[k] && S.result[k]) err("a result without a ray");
+                        if (k && S.pushed[k] && ambiguous(S.pushed[k])) err("an ambiguous verdict took the short cut");
+                        S.pushed[k] = 0; S.result[k] = 0;
+                    }
+                    S.bounce++;
+                    if (S.bounce < path_len(S.pixel, S.sample) || !escapes(S.pixel, S.sample)) err("a path that has not left the scene took the short cut");
+                } else {
+                    if (S.light != 1u + hash32(S.pixel * 53u + S.sample * 19u)) err("a sample was finished before its path was over");
+                    S.light = 0;
+                }
                 Pixel& P = pixels[S.pixel];
                 if (P.done != S.sample) err("a pixel's samples ran out of order");
                 P.done++;
@@ -195,7 +223,10 @@ struct Model {
                     const uint32_t h = hash32(S.pixel * 13u + S.sample * 5u + S.bounce);
                     pend_shadow = (h & 1u) != 0;
                     pend_light = (h & 6u) == 6u;
-                    if (S.bounce >= path_len(S.pixel, S.sample)) donep = true;
+                    if (S.bounce >= path_len(S.pixel, S.sample)) {
+                        donep = true;
+                        if (escapes(S.pixel, S.sample)) pend_shadow = pend_light = false;      // (a ray that left the scene starts no query)
+                    }
                 }
                 if (donep && (pend_shadow || pend_light)) {
                     S.fin_next = true;
@@ -320,9 +351,9 @@ struct Model {
         }
         if (px.ctl[ER_RING_COUNT] != 0) bad++;
         const uint32_t lost = rays_pushed.load() - rays_traced.load();
-        printf("variant %u slots %u pixels %u samples %u: %u pixels short, %u rays pushed, %u lost, %u protocol errors, %u ring faults, laps: ray ring %u, pixel ring %u\n",
+        printf("variant %u slots %u pixels %u samples %u: %u pixels short, %u rays pushed, %u lost, %u protocol errors, %u ring faults, laps: ray ring %u, pixel ring %u, short cuts %u\n",
                variant, in_slots, n_pixels, n_samples, short_px, rays_pushed.load(), lost, errors.load(), bad, rq.ctl[ER_RING_TAIL] >> rq.log2,
-               px.ctl[ER_RING_TAIL] / px_cap);
+               px.ctl[ER_RING_TAIL] / px_cap, shortcuts.load());
         return (short_px || lost || errors.load() || bad) ? 1 : 0;
     }
 };

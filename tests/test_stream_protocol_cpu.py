@@ -1,7 +1,7 @@
 """The streaming schedule's hand-off protocol as a host-thread model under contention and under ThreadSanitizer.
 
-tests/native/ring_model.cpp runs ONE workgroup of csrc/er_stream.hip on CPU threads: ray ring, shade ring and the HBM pixel ring with
-its "entry read" bits -- on the SAME functions the kernel uses (csrc/er_ring.h, compiled with -DER_RING_HOST_MODEL) -- with capacities of 4 to 16 cells, so every ring wraps hundreds to
+tests/native/ring_model.cpp runs ONE workgroup of csrc/er_stream.hip on CPU threads: ray ring, shade ring, finish ring (with the tracers' short cut for paths
+that have left the scene) and the HBM pixel ring with its "entry read" bits -- on the SAME functions the kernel uses (csrc/er_ring.h, compiled with -DER_RING_HOST_MODEL) -- with capacities of 4 to 16 cells, so every ring wraps hundreds to
 thousands of times per run, and with the slot records and per-pixel state in plain memory, so that ThreadSanitizer
 reports any hand-off the protocol leaves unordered.  This is where the protocol is argued exact; the GPU
 suite only keeps one regression run per call pattern.  No GPU needed."""
@@ -51,6 +51,7 @@ def test_every_ray_once_every_sample_in_order_every_ring_empty(model, cfg):
         assert "0 pixels short" in r.stdout and " 0 lost, 0 protocol errors, 0 ring faults" in r.stdout
         laps = int(r.stdout.split("laps: ray ring ")[1].split(",")[0])
         assert laps >= 50, r.stdout        # the point of the small capacities: positions come round again, many times
+        assert int(r.stdout.split("short cuts ")[1]) > 0, r.stdout       # escaped paths did go from the tracers straight to the finish ring
 
 
 def test_thread_sanitizer_finds_no_unordered_hand_off(model_tsan):
