@@ -14,9 +14,15 @@
 //     (one record per slot, StState below); slots, ring and the planes of the workgroup's pixels are only ever touched
 //     by waves of that workgroup -- i.e. of one CU, which share the vector L1 -- so workgroup-scope release/acquire (a wait
 //     for the wave's own stores) is all the ordering needed;
-//   * shader waves and tracer waves feed each other through two rings in LDS: rays to trace (closest-hit and shadow queries)
-//     and slots to shade.  A per-slot counter in LDS holds the number of rays of the slot still in flight; the tracer that
-//     finishes the last one appends the slot to the shade ring;
+//   * shader waves and tracer waves feed each other through three rings in LDS: rays to trace (closest-hit and shadow queries),
+//     slots to shade, and slots whose sample is to be FINISHED.  A per-slot word in LDS holds the number of rays of the slot
+//     still in flight and what the tracers learnt about them; the tracer that finishes the last one appends the slot to the
+//     shade ring -- or, when the path has left the scene and no shadow verdict is ambiguous, straight to the finish ring.
+//     A shader wave runs either a SHADING step (the bounce, for a batch of slots whose ray hit something) or a FINISHING step
+//     (sky look-up of escaped paths, accumulation into the planes, pixel exchange, next camera ray) for a batch of its own:
+//     one path in 4.5 steps ends, and run inline that code kept the whole wave busy for a fifth of its lanes;
+//   * wave-level ring work is batched on the tracer side too: a finished ray stays in its lane's registers until the wave's
+//     next ring visit (every `refill_min` idle lanes), where publishing results and taking new rays share the cost;
 //   * every ring is the bounded queue of er_ring.h: cells carry (lap, full, payload), producers and consumers CHECK the cell
 //     they were given and nobody clears anything, so no entry can be lost, duplicated or read from the wrong lap whatever the
 //     interleaving -- no timing assumption (the host-thread model of the same functions, tests/native/ring_model.cpp, runs
@@ -66,7 +72,8 @@ namespace {
 static_assert(ER_STREAM_SLOTS <= (1u << ST_SLOT_BITS) && ST_SLOT_BITS + 2 <= ER_RING_PAYLOAD_BITS, "a local slot must fit the ring payload");
 #define ST_SLOT_MASK ((1u << ST_SLOT_BITS) - 1u)
 // ray-ring entry = local slot | kind << 11: 0 closest hit, 1 HDRI shadow query, 2 point-light query;
-// shade-ring entry = local slot | fin << 11 (fin: the slot is only finalised, ER_WF_FINALIZE_ONLY)
+// shade-ring entry = local slot | fin << 11 (fin: the slot is only finalised, ER_WF_FINALIZE_ONLY);
+// finish-ring entry = local slot | esc << 11 (esc: put there by a tracer -- the shading step's part for a ray that left the scene is still to do)
 #define ST_FIN 0x100u            // the same flag in s_wait
 // flags the TRACERS add to a slot's s_wait word while its rays finish (the tracer that takes the count to zero sees them all):
 #define ST_ESC 0x200u            //   the closest-hit ray found no candidate at all: the path has left the scene
@@ -83,7 +90,8 @@ static_assert((1u << ST_SQ_LOG2) >= ER_STREAM_SLOTS, "the shade ring must hold e
 static_assert((1u << ST_RQ_LOG2) >= ER_STREAM_SLOTS && (1u << ST_RQ_LOG2) >= 4u * 192u, "ray ring too small");
 // Static issue priority (s_setprio once, before the loop: arbitration between the waves of a SIMD is by priority, then age).  A
 // shading step is ~6 000 vector instructions on a SIMD it shares with two or three tracer waves and was 138 k cycles long
-// (profiles/r03_shader_sections_c2.log); with the shader waves at priority 1 five of them feed eleven tracer waves:
+// (profiles/r03_shader_sections_c2.log); with the shader waves at priority 1 five of them fed eleven tracer waves (four feed twelve
+// since finished and escaped paths have batches of their own: 1 557 -> 1 627 Msamples/s, profiles/r03_ab_escaped_paths_to_finish_ring.log):
 // C2 1 367 -> 1 396, C5 983 -> 1 037, 4K 1 417 -> 1 435, 720p 1 283 -> 1 276 Msamples/s (profiles/r03_ab_wave_priority_*.log; at 10 + 6
 // the same priority LOSES 6 %: the tracers then wait for issue slots).  Tracer waves at priority 1 instead: +1 %.
 #ifndef ER_SHADER_PRIO
