@@ -306,7 +306,10 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         s->stream_blocks = (uint32_t)prop.multiProcessorCount;
-        s->stream_tracers = 12;      // 12 tracer + 4 shader waves (shader waves at issue priority 1; finished and escaped paths handled in batches of their own, er_stream.hip); before: 11 + 5, round 2: 10 + 6
+        // 12 tracer + 4 shader waves (shader waves at issue priority 1; finished and escaped paths handled in batches of their own,
+        // er_stream.hip); before: 11 + 5, round 2: 10 + 6.  With the point-light extension a shading step is a third longer (a second
+        // BRDF evaluation, a second shadow query): 11 + 5 there (C5: 1 188 vs 1 130 Msamples/s, profiles/r03_ab_split_by_config.log)
+        s->stream_tracers = lights_on ? 11 : 12;
         if (const char* e = getenv("ER_STREAM_TRACERS")) s->stream_tracers = (uint32_t)std::min(13, std::max(1, atoi(e)));   // tuning knob
         const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
         if ((rc = upload(s->d_wf4, nullptr, slots * er_stream_record_bytes(lights_on) / sizeof(float4), s->stream)) != ER_OK) return rc;
