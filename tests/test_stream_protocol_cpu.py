@@ -15,15 +15,23 @@ SRC = os.path.join(ROOT, "tests", "native", "ring_model.cpp")
 HDR = os.path.join(ROOT, "elevenrender_amd", "csrc", "er_ring.h")
 
 
-def _build(tmp, name, flags):
+def _build(tmp, name, flags, guard_log2=25):
+    """guard = polls (one sched_yield each) a ring wait may last before the model calls it a protocol fault.  The checked protocol
+    never needs it, so it is long -- a thread of the model can be off its core for a while on a busy machine, and a short guard
+    once failed a correct run there.  The negative control needs a short one: its lost entries are waited for until it expires."""
     exe = str(tmp / name)
-    subprocess.run(["g++", "-std=c++17", "-pthread", "-DER_RING_HOST_MODEL", "-DER_RING_GUARD=(1u<<19)"] + flags + [SRC, "-o", exe], check=True)
+    subprocess.run(["g++", "-std=c++17", "-pthread", "-DER_RING_HOST_MODEL", f"-DER_RING_GUARD=(1u<<{guard_log2})"] + flags + [SRC, "-o", exe], check=True)
     return exe
 
 
 @pytest.fixture(scope="module")
 def model(tmp_path_factory):
     return _build(tmp_path_factory.mktemp("ring"), "ring_model", ["-O2"])
+
+
+@pytest.fixture(scope="module")
+def model_short_guard(tmp_path_factory):
+    return _build(tmp_path_factory.mktemp("ring_neg"), "ring_model_neg", ["-O2"], guard_log2=19)
 
 
 @pytest.fixture(scope="module")
@@ -62,7 +70,8 @@ def test_thread_sanitizer_finds_no_unordered_hand_off(model_tsan):
         assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
 
 
-def test_the_model_has_teeth_round_2_producers_lose_rays_on_small_rings(model):
+def test_the_model_has_teeth_round_2_producers_lose_rays_on_small_rings(model_short_guard):
+    model = model_short_guard
     """Negative control: producers that overwrite a cell without waiting for the previous lap's reader (the ring protocol of
     round 2, safe there only by a timing argument) lose or duplicate entries once the ring is small enough to be lapped.  The
     outcome depends on thread timing, so several runs are made and at least one must be caught."""
