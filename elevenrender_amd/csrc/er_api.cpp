@@ -645,12 +645,23 @@ static int er_read_pass_impl(ErScene* s, int pass, float* dst) {
     if (pass < 0 || pass >= ER_PASS_COUNT) return fail(ER_ERR_INVALID_ARG, "er_read_pass: pass out of range");
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_read_pass: NULL scene");
     size_t npx = (size_t)s->x_res * s->y_res;
-    return read_back(s, s->d_passes.p + (size_t)pass * npx, dst, npx * sizeof(float4), "er_read_pass");
+    // the device keeps the accumulated passes interleaved per pixel (er_pass_index, er_device.h): the plane the ABI hands out is
+    // gathered into a staging plane first, on the library's stream (so it is the same sample-boundary snapshot as before)
+    {
+        std::lock_guard<std::mutex> lk(s->mtx);
+        if (!s->begun) return fail(ER_ERR_STATE, "er_read_pass: er_render_begin has not succeeded");
+        HIP_TRY(hipSetDevice(s->device));
+        int rc;
+        if (s->d_plane.n < npx && (rc = upload(s->d_plane, nullptr, npx, s->stream)) != ER_OK) return rc;
+        er_launch_plane(s->dev, pass, s->d_plane.p, s->stream);
+        HIP_TRY(hipGetLastError());
+    }
+    return read_back(s, s->d_plane.p, dst, npx * sizeof(float4), "er_read_pass");
 }
 // ---- checkpoint / resume: passes + samples + rng are the whole progressive state (reference src/kernel.h:44-46) ----
 namespace {
 struct StateHeader {
-    char magic[8];            // "ERSTATE1"
+    char magic[8];            // "ERSTATE2" (2: the accumulated passes interleaved per pixel, er_pass_index; a snapshot of layout 1 is refused)
     uint32_t x_res, y_res, passes, reserved;
     uint64_t bytes;
     uint8_t pad[32];
@@ -676,7 +687,7 @@ static int er_state_export_impl(ErScene* s, void* dst, uint64_t bytes) {
     HIP_TRY(hipSetDevice(s->device));
     const size_t npx = (size_t)s->x_res * s->y_res;
     StateHeader h{};
-    memcpy(h.magic, "ERSTATE1", 8);
+    memcpy(h.magic, "ERSTATE2", 8);
     h.x_res = s->x_res; h.y_res = s->y_res; h.passes = ER_PASS_COUNT; h.bytes = state_bytes(s);
     uint8_t* p = (uint8_t*)dst;
     memcpy(p, &h, sizeof(h));
@@ -698,7 +709,7 @@ static int er_state_import_impl(ErScene* s, const void* src, uint64_t bytes) {
     StateHeader h;
     if (bytes < sizeof(h)) return fail(ER_ERR_INVALID_ARG, "er_state_import: truncated snapshot");
     memcpy(&h, src, sizeof(h));
-    if (memcmp(h.magic, "ERSTATE1", 8) != 0) return fail(ER_ERR_INVALID_ARG, "er_state_import: not a snapshot (bad magic)");
+    if (memcmp(h.magic, "ERSTATE2", 8) != 0) return fail(ER_ERR_INVALID_ARG, "er_state_import: not a snapshot of this library version (bad magic)");
     if (h.x_res != s->x_res || h.y_res != s->y_res || h.passes != ER_PASS_COUNT)
         return fail(ER_ERR_INVALID_ARG, "er_state_import: the snapshot is of a " + std::to_string(h.x_res) + "x" + std::to_string(h.y_res) + " frame");
     if (h.bytes != state_bytes(s) || bytes < h.bytes) return fail(ER_ERR_INVALID_ARG, "er_state_import: truncated snapshot");
@@ -731,16 +742,16 @@ static int er_denoise_impl(ErScene* s, uint32_t levels, float colour_sigma) {
     ScopedDevBuf<float4> tmp;
     int rc;
     if ((rc = upload(tmp, (const void*)nullptr, npx, s->stream)) != ER_OK) return rc;
-    const float4* beauty = s->d_passes.p + (size_t)ER_PASS_BEAUTY * npx;
-    const float4* normal = s->d_passes.p + (size_t)ER_PASS_NORMAL * npx;
-    float4* out = s->d_passes.p + (size_t)ER_PASS_DENOISE * npx;
+    const float4* beauty = s->d_passes.p + er_pass_index(npx, ER_PASS_BEAUTY, 0);      // (interleaved passes: stride 4, er_device.h)
+    const float4* normal = s->d_passes.p + er_pass_index(npx, ER_PASS_NORMAL, 0);
+    float4* out = s->d_passes.p + er_pass_index(npx, ER_PASS_DENOISE, 0);
     // ping-pong so that the last level lands in the DENOISE plane
     const float4* src = beauty;
     for (uint32_t k = 0; k < levels; k++) {
         float4* dst = ((levels - 1 - k) & 1u) ? tmp.p : out;
         // the colour edge-stop tightens with the level, as the residual noise shrinks
         const float kc = 1.0f / (colour_sigma * colour_sigma) * (float)(1u << k);
-        er_launch_atrous(src, normal, dst, (int)s->x_res, (int)s->y_res, 1 << k, kc, s->stream);
+        er_launch_atrous(src, src == beauty ? 4 : 1, normal, 4, dst, (int)s->x_res, (int)s->y_res, 1 << k, kc, s->stream);
         src = dst;
     }
     HIP_TRY(hipGetLastError());

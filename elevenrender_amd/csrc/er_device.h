@@ -67,13 +67,23 @@ struct DevScene {
     const ErPointLight* lights;
     uint32_t light_count;
     // per-pixel state
-    float4* passes;             // ER_PASS_COUNT planes of x_res*y_res float4
+    float4* passes;             // ER_PASS_COUNT x (x_res*y_res) float4 in the layout of er_pass_index (below): NOT plane after plane
     uint32_t* samples;
     uint32_t* rng;
     const uint32_t* owned_tiles;
     uint32_t owned_tile_count;
     DevCounters* counters;
 };
+
+// Where pass `pass` of pixel `idx` lives in DevScene::passes.  The four planes a finished sample is accumulated into -- beauty, normal,
+// tangent, bitangent -- are INTERLEAVED per pixel (64 bytes: one half cache line instead of four lines for the read-modify-write of the
+// accumulate step: +1.8 % on C2, profiles/r03_ab_interleaved_planes_probe.log); the DENOISE plane, which only er_denoise writes, follows
+// as a plane of its own.  Every access goes through this function; the ABI's plane-after-plane view is made at the boundary
+// (er_read_pass gathers a plane, er_pack / er_unpack address pixels one by one, the checkpoint blob is the raw buffer).
+__host__ __device__ __forceinline__ size_t er_pass_index(size_t npx, int pass, size_t idx) {
+    return pass == ER_PASS_DENOISE ? 4 * npx + idx : idx * 4 + (size_t)(pass == ER_PASS_BEAUTY ? 0 : pass - 1);
+}
+
 
 namespace erd {
 

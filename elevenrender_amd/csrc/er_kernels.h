@@ -12,7 +12,8 @@ hipError_t er_probe_kernels(const char** which);
 hipError_t er_probe_wavefront(const char** which);
 hipError_t er_probe_fused(const char** which);
 hipError_t er_probe_gpu_build(const char** which);
-void er_launch_atrous(const float4* src, const float4* normal, float4* dst, int w, int h, int step, float kc, hipStream_t stream);
+void er_launch_atrous(const float4* src, int src_stride, const float4* normal, int normal_stride, float4* dst, int w, int h, int step, float kc, hipStream_t stream);
+void er_launch_plane(const DevScene& S, int pass, float4* dst, hipStream_t stream);      // DevScene::passes -> one contiguous plane
 void er_launch_debug_hit(const DevScene& S, const float* o, const float* d, uint32_t n, int32_t* tri, float* pos, float* dist, hipStream_t stream);
 void er_launch_render(const DevScene& S, uint32_t n_samples, bool count, hipStream_t stream);
 void er_launch_pack(const DevScene& S, const uint32_t* tiles, uint32_t ntiles, int pass, void* dst, hipStream_t stream);

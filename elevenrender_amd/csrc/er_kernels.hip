@@ -28,7 +28,7 @@ __global__ void er_setup_kernel(DevScene S) {
     uint32_t npx = S.x_res * S.y_res;
     if (idx >= npx) return;
     S.rng[idx] = jenkins_u32(idx + 1);
-    for (int p = 0; p < ER_PASS_COUNT; p++) S.passes[(size_t)p * npx + idx] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    for (int p = 0; p < ER_PASS_COUNT; p++) S.passes[er_pass_index(npx, p, idx)] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
     S.samples[idx] = 1;
 }
 
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void er_pack_kernel(DevScene S, const uint32_t*
     const uint32_t tx = tile % S.tiles_x, ty = tile / S.tiles_x;
     const uint32_t px = tx * ER_TILE + (lane & 7), py = ty * ER_TILE + (lane >> 3);
     float4 v = make_float4(0, 0, 0, 0);
-    if (px < S.x_res && py < S.y_res) v = S.passes[(size_t)pass * S.x_res * S.y_res + (size_t)py * S.x_res + px];
+    if (px < S.x_res && py < S.y_res) v = S.passes[er_pass_index((size_t)S.x_res * S.y_res, pass, (size_t)py * S.x_res + px)];
     dst[(size_t)blockIdx.x * 64 + lane] = v;
 }
 __global__ __launch_bounds__(64) void er_unpack_kernel(DevScene S, const uint32_t* tiles, int pass, const float4* src) {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64) void er_unpack_kernel(DevScene S, const uint32_
     const uint32_t tx = tile % S.tiles_x, ty = tile / S.tiles_x;
     const uint32_t px = tx * ER_TILE + (lane & 7), py = ty * ER_TILE + (lane >> 3);
     if (px < S.x_res && py < S.y_res)
-        S.passes[(size_t)pass * S.x_res * S.y_res + (size_t)py * S.x_res + px] = src[(size_t)blockIdx.x * 64 + lane];
+        S.passes[er_pass_index((size_t)S.x_res * S.y_res, pass, (size_t)py * S.x_res + px)] = src[(size_t)blockIdx.x * 64 + lane];
 }
 
 // ---- debug: closest hit of arbitrary rays through the exact routine (include/eleven_hip_debug.h) ----
@@ -197,19 +197,20 @@ void er_launch_render(const DevScene& S, uint32_t n_samples, bool count, hipStre
 // not on this path and has no arithmetic to match).  One launch per level; level k taps a 5x5 B3-spline stencil with
 // holes of 2^k pixels (Dammertz et al. 2010).  Edge-stopping weights are rational -- w = 1 / (1 + kc |dc|^2) and
 // max(0, n.n')^2 -- so the filter is plain IEEE arithmetic (tests/test_gpu_denoise.py replays it in numpy, bit for bit).
-__global__ __launch_bounds__(256) void er_atrous_kernel(const float4* __restrict__ src, const float4* __restrict__ normal, float4* __restrict__ dst,
-                                                         int w, int h, int step, float kc) {
+// (src and normal are read with a stride in float4 units: 4 for a pass of the interleaved block of DevScene::passes, 1 for a plane)
+__global__ __launch_bounds__(256) void er_atrous_kernel(const float4* __restrict__ src, int src_stride, const float4* __restrict__ normal, int normal_stride,
+                                                         float4* __restrict__ dst, int w, int h, int step, float kc) {
     const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= w || y >= h) return;
     const float kernel[5] = {1.0f / 16.0f, 1.0f / 4.0f, 3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
-    const float4 c = src[(size_t)y * w + x], n = normal[(size_t)y * w + x];
+    const float4 c = src[((size_t)y * w + x) * src_stride], n = normal[((size_t)y * w + x) * normal_stride];
     float sx = 0, sy = 0, sz = 0, sw = 0;
     for (int j = -2; j <= 2; j++)
         for (int i = -2; i <= 2; i++) {
             int qx = x + i * step, qy = y + j * step;
             qx = qx < 0 ? 0 : (qx >= w ? w - 1 : qx);
             qy = qy < 0 ? 0 : (qy >= h ? h - 1 : qy);
-            const float4 cq = src[(size_t)qy * w + qx], nq = normal[(size_t)qy * w + qx];
+            const float4 cq = src[((size_t)qy * w + qx) * src_stride], nq = normal[((size_t)qy * w + qx) * normal_stride];
             const float dx = c.x - cq.x, dy = c.y - cq.y, dz = c.z - cq.z;
             const float d2 = dx * dx + dy * dy + dz * dz;
             const float wc = 1.0f / (1.0f + kc * d2);
@@ -222,8 +223,19 @@ __global__ __launch_bounds__(256) void er_atrous_kernel(const float4* __restrict
         }
     dst[(size_t)y * w + x] = make_float4(sx / sw, sy / sw, sz / sw, c.w);
 }
-void er_launch_atrous(const float4* src, const float4* normal, float4* dst, int w, int h, int step, float kc, hipStream_t stream) {
-    hipLaunchKernelGGL(er_atrous_kernel, dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, stream, src, normal, dst, w, h, step, kc);
+void er_launch_atrous(const float4* src, int src_stride, const float4* normal, int normal_stride, float4* dst, int w, int h, int step, float kc, hipStream_t stream) {
+    hipLaunchKernelGGL(er_atrous_kernel, dim3((w + 15) / 16, (h + 15) / 16), dim3(256), 0, stream, src, src_stride, normal, normal_stride, dst, w, h, step, kc);
+}
+
+// one pass of every pixel as a plane (the ABI's view; er_read_pass)
+__global__ __launch_bounds__(256) void er_plane_kernel(DevScene S, int pass, float4* __restrict__ dst) {
+    const size_t npx = (size_t)S.x_res * S.y_res, idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < npx) dst[idx] = S.passes[er_pass_index(npx, pass, idx)];
+}
+void er_launch_plane(const DevScene& S, int pass, float4* dst, hipStream_t stream) {
+    const size_t npx = (size_t)S.x_res * S.y_res;
+    if (npx == 0) return;
+    hipLaunchKernelGGL(er_plane_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, stream, S, pass, dst);
 }
 
 void er_launch_pack(const DevScene& S, const uint32_t* tiles, uint32_t ntiles, int pass, void* dst, hipStream_t stream) {

@@ -169,6 +169,7 @@ struct ErScene {
     DevScene dev{};
     ErAccelInfo accel{};
     DevBuf<float4> d_nodes, d_nodes8, d_isect, d_attr, d_passes;
+    DevBuf<float4> d_plane;      // staging: one pass gathered as a plane for er_read_pass
     DevBuf<ErMaterial> d_materials;
     DevBuf<ErPointLight> d_lights;
     DevBuf<DevTex> d_textures;
@@ -207,7 +208,7 @@ struct ErScene {
         return t;
     }
     void release_device() {
-        d_nodes.release(); d_nodes8.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_materials.release();
+        d_nodes.release(); d_nodes8.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_plane.release(); d_materials.release();
         d_textures.release(); d_tex_pool.release(); d_lights.release(); d_cdf.release(); d_samples.release(); d_rng.release();
         d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_deal.release(); d_ray_log.release();
         for (auto& kv : d_rank_tiles) kv.second.release();

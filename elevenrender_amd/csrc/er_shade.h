@@ -64,19 +64,6 @@ static inline bool er_ext_active(const DevScene& S) {
 
 // End of a path, src/kernel.cpp:597-645: clamp to [0,10], NaN gate, running mean over `sa` (which starts at 1, so after
 // n samples the planes hold sum/(n+1)); the DENOISE plane is never written.  Returns the new sample count.
-// A pixel's planes are touched once per finished sample -- a pass of ~28 GB of other traffic apart -- so their loads and stores carry
-// the non-temporal hint (they stream past the caches instead of displacing tree and slot-record lines): +1.1 % on C2
-// (profiles/r03_ab_nontemporal_planes.log; the same hint on the sample-count and RNG-state words as well: less, +0.6 %).
-// (Only where the including kernel asks for it -- ER_ACCUMULATE_NONTEMPORAL, the streaming schedule: on a small frame, whose planes
-// live in the caches, the fused schedule lost 5 % with it.)
-#ifdef ER_ACCUMULATE_NONTEMPORAL
-typedef float er_f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 er_plane_load(const float4* p) { const er_f4v v = __builtin_nontemporal_load((const er_f4v*)p); return make_float4(v.x, v.y, v.z, v.w); }
-__device__ __forceinline__ void er_plane_store(float4* p, float4 a) { const er_f4v v = {a.x, a.y, a.z, a.w}; __builtin_nontemporal_store(v, (er_f4v*)p); }
-#else
-__device__ __forceinline__ float4 er_plane_load(const float4* p) { return *p; }
-__device__ __forceinline__ void er_plane_store(float4* p, float4 a) { *p = a; }
-#endif
 ERD uint32_t accumulate_sample(const DevScene& S, uint32_t idx, uint32_t sa, F3 light, F3 aov_n, F3 aov_t, F3 aov_b) {
     const size_t npx = (size_t)S.x_res * S.y_res;
     light = f3(clampf(light.x, 0, 10), clampf(light.y, 0, 10), clampf(light.z, 0, 10));
@@ -87,11 +74,11 @@ ERD uint32_t accumulate_sample(const DevScene& S, uint32_t idx, uint32_t sa, F3 
         const int planes[4] = {ER_PASS_BEAUTY, ER_PASS_NORMAL, ER_PASS_TANGENT, ER_PASS_BITANGENT};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            float4* pp = S.passes + (size_t)planes[q] * npx + idx;
-            float4 p = er_plane_load(pp);
+            float4* pp = S.passes + er_pass_index(npx, planes[q], idx);      // (the four are neighbours: one 64-byte run)
+            float4 p = *pp;
             if (sa > 0) { p.x *= k; p.y *= k; p.z *= k; }
             p.x += vals[q].x / inv; p.y += vals[q].y / inv; p.z += vals[q].z / inv;
-            er_plane_store(pp, p);
+            *pp = p;
         }
         sa++;
     }

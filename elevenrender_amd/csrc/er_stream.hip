@@ -43,7 +43,6 @@
 #include "er_kernels.h"
 #include "er_wavefront.h"
 #include "er_trav.h"
-#define ER_ACCUMULATE_NONTEMPORAL 1      // (er_shade.h: plane accesses of the accumulate step stream past the caches)
 #include "er_shade.h"
 #include "er_stream.h"
 #include "er_ring.h"

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, Wf
                     const int planes[4] = {ER_PASS_BEAUTY, ER_PASS_NORMAL, ER_PASS_TANGENT, ER_PASS_BITANGENT};
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        float4* pp = S.passes + (size_t)planes[q] * npx + idx;
+                        float4* pp = S.passes + er_pass_index(npx, planes[q], idx);
                         float4 p = *pp;
                         if (sa > 0) { p.x *= k; p.y *= k; p.z *= k; }
                         p.x += vals[q].x / inv; p.y += vals[q].y / inv; p.z += vals[q].z / inv;
