@@ -19,8 +19,8 @@ triangle test, event counts from an instrumented replay of the same samples.
   roofline.peak = 8 TB/s (HBM3E spec, MI355X_MICROARCH.md); roofline.peak_measured = a streaming copy / read kernel timed
       in this job (er_measure_hbm_peak).
 
-With --gpus N the frame's 8x8 pixel tiles are sharded over N ranks (one process per GPU, launched by
-torch.distributed.run); there is no collective in the timed region -- the RCCL framebuffer gather (all five planes,
+With --gpus N the frame's 8x8 pixel tiles are sharded over N ranks (one process per GPU: under torch.distributed.run when
+the caller used it, otherwise `bench.py --gpus N` starts its own N ranks as a child process, launch_ranks()); there is no collective in the timed region -- the RCCL framebuffer gather (all five planes,
 through the library's own C++ entry er_gather_pass) happens once after it and is reported as readback_ms.
 
 Prints ONE JSON line on rank 0.
@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_TAG = "r03"     # profiles/<tag>_pmc_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
+PROFILE_TAG = "r04"     # profiles/<tag>_pmc_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
 
 
 def trace_bytes(c):
@@ -116,11 +116,59 @@ def cpu_baseline(scene, max_bounces, flags, threads, budget_s=16.0, one_core_bud
     return out
 
 
+def launch_ranks(n):
+    """`bench.py --gpus N` run without a launcher: start the N ranks (one process per GPU) with torch.distributed.run as a CHILD
+    process, pass its output through (rank 0 prints the JSON line) and return its exit code.  Runs before this process has
+    imported torch or touched HIP: nothing that has initialised the GPU is ever replaced (no exec), and the parent never
+    initialises it at all.  Reference shape reproduced by the N ranks: one pass per sample over all pixels
+    (src/kernel.cpp:680-706), the read-back of src/Managers.cpp:287-302 after the gather."""
+    import socket
+    import subprocess
+    rehearsal = os.environ.get("ER_BENCH_REHEARSAL") == "1" or os.environ.get("ER_BENCH_DRY_RUN") == "1"
+    if not rehearsal:
+        import torch   # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"bench.py --gpus {n}: this node shows {have} GPU(s); one process per GPU needs {n} "
+                  f"(ER_BENCH_REHEARSAL=1 rehearses the control flow with all ranks on GPU 0 over gloo)", file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(rank, world):
+    """ER_BENCH_DRY_RUN=1: the ranks join (gloo), agree on who is there, rank 0 prints one line; nothing touches a GPU.
+    Lets the CPU test-suite see that `bench.py --gpus N` really becomes N ranks."""
+    import torch
+    import torch.distributed as dist
+    joined = [rank]
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+        t = torch.zeros(world, dtype=torch.int64)
+        t[rank] = rank + 1
+        dist.all_reduce(t)
+        joined = [int(v) - 1 for v in t.tolist()]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_joined": joined}), flush=True)
+    return 0
+
+
 CONFIGS = {
     # name: (description, default max_bounces, config spp)
     "C1": ("Cornell box, 12 triangles, 256x256", 4, 16),
     "C2": ("1M random-triangle soup + 2048x1024 sky HDRI, 1920x1080", 8, 256),
-    "C4": ("9.68M triangles (10 000 instances of a 968-triangle smooth blob, flattened) + sky HDRI, 3840x2160", 8, 1024),
+    "C4": ("10M triangles (10 000 instances of a 1 000-triangle smooth blob, flattened) + sky HDRI, 3840x2160", 8, 1024),
     "C5": ("1M-triangle soup, 64 textured materials (192 value-noise textures), 256 point lights, MIS on, 1920x1080", 16, 256),
 }
 
@@ -139,7 +187,7 @@ def make_scene(args, scenes, abi):
     elif args.config == "C4":
         w, h = args.width or 3840, args.height or 2160
         sc = scenes.blob_instances(x_res=w, y_res=h)
-        what = f"C4: {sc.tri_count} triangles (10 000 instances of a 968-triangle smooth-normal blob, flattened; the config says 10M) + sky HDRI, {w}x{h}"
+        what = f"C4: {sc.tri_count} triangles (10 000 instances of a 1 000-triangle smooth-normal blob, flattened) + sky HDRI, {w}x{h}"
     else:
         w, h = args.width or 1920, args.height or 1080
         sc = scenes.torture(args.tris, w, h, seed=12345)
@@ -174,11 +222,16 @@ def main():
     args = ap.parse_args()
     max_bounces = args.max_bounces or CONFIGS[args.config][1]
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))       # `python3 bench.py --gpus N` as typed: this process only starts the N ranks
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if os.environ.get("ER_BENCH_DRY_RUN") == "1":
+        sys.exit(dry_run(rank, world))
 
     import torch   # device sync, torch.distributed (RCCL) -- plumbing only
     import numpy as np
@@ -400,20 +453,31 @@ def main():
 
         traffic = None
         traffic_source = None
-        # HBM bytes from rocprofv3 PMC passes (tools/record_run.sh; the wavefront schedule's set was recorded with --schedule wavefront)
-        tf = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}{'wf' if sched == 'wavefront' else ''}_pmc_traffic.json")
-        if os.path.exists(tf) and world == 1 and args.config == "C2" and args.tris == 1_000_000 and not (args.width or args.height):
-            try:
-                tj = json.load(open(tf))
-                if sched == "wavefront":
-                    traffic = tj.get("er_wf_trace_hbm_bytes_per_launch")
-                    traffic_source = f"profiles/{os.path.basename(tf)}: PMC passes of an earlier run of this command, replayed (not measured in this run)"
-                elif sched == "stream" and tj.get("er_stream_kernel_hbm_bytes_per_step"):
-                    # one launch of the streaming kernel runs all K steps of the call; the PMC passes measured bytes per step
-                    traffic = tj["er_stream_kernel_hbm_bytes_per_step"] * args.steps / launches
-                    traffic_source = f"profiles/{os.path.basename(tf)}: bytes per step from PMC passes of an earlier run of this command x the steps of this launch, replayed (not measured in this run)"
-            except Exception:
-                traffic = None
+        # HBM-side bytes from rocprofv3 PMC passes of THIS command line (tools/pmc_passes.sh + tools/pmc_traffic.py; counters cannot be
+        # collected inside a timed run): replayed, and only for the exact workload they were recorded on
+        standard = args.tris == 1_000_000 and not (args.width or args.height) and not args.max_bounces and not args.gpu_build and world == 1 and shard_world == 1
+        cfg_key = args.config + ("_nolights" if args.config == "C5" and args.no_lights else "")
+        if sched == "stream" and standard:
+            for tag in (PROFILE_TAG, "r03"):
+                tf = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+                if not os.path.exists(tf):
+                    continue
+                try:
+                    tj = json.load(open(tf))
+                    per_step = (tj.get(cfg_key) or {}).get("er_stream_kernel_hbm_bytes_per_step") or (tj.get("er_stream_kernel_hbm_bytes_per_step") if cfg_key == "C2" else None)
+                    if per_step:
+                        # one launch of the streaming kernel runs all K steps of the call; the PMC passes measured bytes per step
+                        traffic = per_step * args.steps / launches
+                        traffic_source = (f"profiles/{os.path.basename(tf)} [{cfg_key}]: bytes per step from PMC passes of an earlier run of this command x the "
+                                          f"steps of this launch, replayed (not measured in this run)")
+                        break
+                except Exception:
+                    traffic = None
+        elif sched == "wavefront" and standard and args.config == "C2":
+            tf = os.path.join(ROOT, "profiles", "r02wf_pmc_traffic.json")
+            if os.path.exists(tf):
+                traffic = json.load(open(tf)).get("er_wf_trace_hbm_bytes_per_launch")
+                traffic_source = f"profiles/{os.path.basename(tf)}: PMC passes of an earlier run of this command, replayed (not measured in this run)"
         value = samples / elapsed / 1e6
         result = {
             "metric": "Msamples/sec (rays traced x bounces) at 1920x1080, 1M-tri scene",
@@ -473,7 +537,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or host_cores()
-            # C4: ONE reference-style BVH build of the 9.68 M triangles (the expensive part, not timed), then the same bounded sample
+            # C4: ONE reference-style BVH build of the 10 M triangles (the expensive part, not timed), then the same bounded sample
             # of rows on all cores; the one-core leg would need a second build and is left out there
             result["cpu_baseline"] = cpu_baseline(scene, max_bounces, ext_flags, threads, args.cpu_budget, one_core=args.config != "C4")
             result["gpu_over_cpu"] = round(value / max(result["cpu_baseline"]["value"], 1e-12), 1)

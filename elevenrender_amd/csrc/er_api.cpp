@@ -120,6 +120,14 @@ void er_scene_destroy(ErScene* s) {
     delete s;
 }
 
+// which deal of tiles the streaming schedule uses for a share of `owned_tiles` tiles on `blocks` workgroups
+static bool stream_xcd_aware(size_t owned_tiles, uint32_t blocks) {
+    const char* xe = getenv("ER_STREAM_XCD_TILES");        // A/B knob: 0 = tiles dealt round-robin to the workgroups (round 2)
+    // (a share with no more pixels than slots -- an eighth of a 1080p frame -- has nothing waiting in its pixel rings; there the
+    // plain round-robin deal balances a little better: 1.392 vs 1.41 ms per pass, profiles/r03_ab_sim_world8_knobs.log)
+    return xe ? atoi(xe) != 0 : owned_tiles * 64 > (size_t)blocks * ER_STREAM_SLOTS;
+}
+
 static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     if (!s || !p) return fail(ER_ERR_INVALID_ARG, "er_render_begin: NULL argument");
     std::lock_guard<std::mutex> lk(s->mtx);
@@ -286,8 +294,16 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
             cus = std::max(1, cus);
             if (px < 150000u) sched = ER_FLAG_FUSED;
-            else if (((owned.size() + (size_t)cus - 1) / (size_t)cus + 4u) * 64u > ER_STREAM_MAX_RING) sched = ER_FLAG_WAVEFRONT;     // (beyond the streaming schedule's pixel rings)
-            else sched = ER_FLAG_STREAM;
+            else {
+                // beyond the streaming schedule's pixel rings -> wavefront.  Decided on the REAL deal of tiles to workgroups, not on an
+                // estimate of its largest share: the XCD-aware deal hands out whole super-tiles and can be less balanced than
+                // ceil(tiles / CUs) (near the limit the estimate chose ER_FLAG_STREAM and er_render_begin then failed
+                // with INVALID_ARG instead of taking the other schedule)
+                std::vector<uint32_t> deal;
+                const uint32_t most = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), (s->x_res + ER_TILE - 1) / ER_TILE, (uint32_t)cus,
+                                                           stream_xcd_aware(owned.size(), (uint32_t)cus), deal);
+                sched = (size_t)most * 64u > ER_STREAM_MAX_RING ? ER_FLAG_WAVEFRONT : ER_FLAG_STREAM;
+            }
         }
         else if (forced & (forced - 1)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: more than one schedule flag");
         s->params.flags = (s->params.flags & ~(uint32_t)(ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM)) | sched;
@@ -323,10 +339,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         // (no minimum beyond one tile: a producer that comes round to a cell whose entry has not been read yet waits for its
         // reader, er_ring.h -- round 2 relied on "a lap of >= 4096 cells takes longer than a read")
         std::vector<uint32_t> deal;
-        const char* xe = getenv("ER_STREAM_XCD_TILES");        // A/B knob: 0 = tiles dealt round-robin to the workgroups (round 2)
-        // (a share with no more pixels than slots -- an eighth of a 1080p frame -- has nothing waiting in its pixel rings; there the
-        // plain round-robin deal balances a little better: 1.392 vs 1.41 ms per pass, profiles/r03_ab_sim_world8_knobs.log)
-        const bool xcd_aware = xe ? atoi(xe) != 0 : owned.size() * 64 > (size_t)s->stream_blocks * ER_STREAM_SLOTS;
+        const bool xcd_aware = stream_xcd_aware(owned.size(), s->stream_blocks);
         const uint32_t most = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), (s->x_res + ER_TILE - 1) / ER_TILE, s->stream_blocks, xcd_aware, deal);
         if ((rc = upload(s->d_deal, deal.data(), deal.size(), s->stream)) != ER_OK) return rc;
         HIP_TRY(hipStreamSynchronize(s->stream));          // (`deal` goes out of scope)
@@ -613,15 +626,20 @@ static int er_render_samples_impl(ErScene* s, uint32_t n) {
     return er_wait(s, nullptr);
 }
 
-static int read_back(ErScene* s, const void* src, void* dst, size_t bytes, const char* who) {
-    if (!s || !dst) return fail(ER_ERR_INVALID_ARG, std::string(who) + ": NULL argument");
-    std::lock_guard<std::mutex> lk(s->mtx);
+// the copy itself; the caller holds s->mtx
+static int read_back_locked(ErScene* s, const void* src, void* dst, size_t bytes, const char* who) {
     if (!s->begun) return fail(ER_ERR_STATE, std::string(who) + ": er_render_begin has not succeeded");
     HIP_TRY(hipSetDevice(s->device));
     // ordered after everything enqueued so far: a sample-boundary snapshot, never a torn read
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return er_scene_stream_status(s, who);
+}
+
+static int read_back(ErScene* s, const void* src, void* dst, size_t bytes, const char* who) {
+    if (!s || !dst) return fail(ER_ERR_INVALID_ARG, std::string(who) + ": NULL argument");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    return read_back_locked(s, src, dst, bytes, who);
 }
 
 static int er_samples_done_impl(ErScene* s, uint32_t* out) {
@@ -644,19 +662,20 @@ static int er_samples_done_impl(ErScene* s, uint32_t* out) {
 static int er_read_pass_impl(ErScene* s, int pass, float* dst) {
     if (pass < 0 || pass >= ER_PASS_COUNT) return fail(ER_ERR_INVALID_ARG, "er_read_pass: pass out of range");
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_read_pass: NULL scene");
-    size_t npx = (size_t)s->x_res * s->y_res;
+    if (!dst) return fail(ER_ERR_INVALID_ARG, "er_read_pass: NULL argument");
     // the device keeps the accumulated passes interleaved per pixel (er_pass_index, er_device.h): the plane the ABI hands out is
-    // gathered into a staging plane first, on the library's stream (so it is the same sample-boundary snapshot as before)
-    {
-        std::lock_guard<std::mutex> lk(s->mtx);
-        if (!s->begun) return fail(ER_ERR_STATE, "er_read_pass: er_render_begin has not succeeded");
-        HIP_TRY(hipSetDevice(s->device));
-        int rc;
-        if (s->d_plane.n < npx && (rc = upload(s->d_plane, nullptr, npx, s->stream)) != ER_OK) return rc;
-        er_launch_plane(s->dev, pass, s->d_plane.p, s->stream);
-        HIP_TRY(hipGetLastError());
-    }
-    return read_back(s, s->d_plane.p, dst, npx * sizeof(float4), "er_read_pass");
+    // gathered into a staging plane first, on the library's stream (so it is the same sample-boundary snapshot as before).
+    // ONE staging plane per scene: the lock is held from the gather kernel to the end of the copy, so that two threads reading
+    // two passes of one scene cannot interleave as gather A, gather B, copy, copy.
+    std::lock_guard<std::mutex> lk(s->mtx);
+    if (!s->begun) return fail(ER_ERR_STATE, "er_read_pass: er_render_begin has not succeeded");
+    size_t npx = (size_t)s->x_res * s->y_res;
+    HIP_TRY(hipSetDevice(s->device));
+    int rc;
+    if (s->d_plane.n < npx && (rc = upload(s->d_plane, nullptr, npx, s->stream)) != ER_OK) return rc;
+    er_launch_plane(s->dev, pass, s->d_plane.p, s->stream);
+    HIP_TRY(hipGetLastError());
+    return read_back_locked(s, s->d_plane.p, dst, npx * sizeof(float4), "er_read_pass");
 }
 // ---- checkpoint / resume: passes + samples + rng are the whole progressive state (reference src/kernel.h:44-46) ----
 namespace {

@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <rccl/rccl.h>   // types and prototypes only: every call goes through the table below (dlopen, no link dependency)
 
 #include "er_scene.h"
@@ -89,10 +90,15 @@ struct Mailbox {
     std::mutex mtx;
     std::condition_variable cv;
     struct Msg { void* copy; size_t bytes; int device; };
-    std::map<std::pair<uint32_t, uint32_t>, Msg> slots;   // (src, dst) -> device copy
+    // (src, dst) -> device copies in the order they were sent.  A FIFO, like the wire it stands for: a rank that gathers pass A
+    // and then pass B before the root has received A leaves both parked, and the root's receives take A, then B -- an
+    // unclaimed message is never dropped or overtaken (with one slot per pair B replaced A and the root's gather of
+    // A silently received B's pixels).
+    std::map<std::pair<uint32_t, uint32_t>, std::deque<Msg>> slots;
     uint64_t bytes_moved = 0, messages = 0;
     ~Mailbox() {
-        for (auto& kv : slots) (void)hipFree(kv.second.copy);
+        for (auto& kv : slots)
+            for (auto& m : kv.second) (void)hipFree(m.copy);
     }
 };
 struct LocalSelf {
@@ -111,10 +117,7 @@ int local_send(void* self, const void* buf, size_t bytes, uint32_t peer, hipStre
     if (e != hipSuccess) { (void)hipFree(copy); return fail(ER_ERR_HIP, std::string("in-process send: ") + hipGetErrorString(e)); }
     {
         std::lock_guard<std::mutex> lk(s->box->mtx);
-        auto key = std::make_pair(s->rank, peer);
-        auto it = s->box->slots.find(key);
-        if (it != s->box->slots.end()) { (void)hipFree(it->second.copy); s->box->slots.erase(it); }      // (an unclaimed older message)
-        s->box->slots[key] = Mailbox::Msg{copy, bytes, dev};
+        s->box->slots[std::make_pair(s->rank, peer)].push_back(Mailbox::Msg{copy, bytes, dev});
         s->box->bytes_moved += bytes;
         s->box->messages++;
     }
@@ -127,12 +130,14 @@ int local_recv(void* self, void* buf, size_t bytes, uint32_t peer, hipStream_t s
     {
         std::unique_lock<std::mutex> lk(s->box->mtx);
         const auto key = std::make_pair(peer, s->rank);
-        static const int wait_s = [] { const char* e = getenv("ER_LOCAL_RECV_TIMEOUT_S"); return e ? std::max(0, atoi(e)) : 120; }();
-        if (!s->box->cv.wait_for(lk, std::chrono::seconds(wait_s), [&] { return s->box->slots.count(key) != 0; }))
+        // (read per call, so that a test can shorten it around ONE negative case without changing it for the whole process)
+        const char* wait_env = getenv("ER_LOCAL_RECV_TIMEOUT_S");
+        const int wait_s = wait_env ? std::max(0, atoi(wait_env)) : 120;
+        if (!s->box->cv.wait_for(lk, std::chrono::seconds(wait_s), [&] { auto f = s->box->slots.find(key); return f != s->box->slots.end() && !f->second.empty(); }))
             return fail(ER_ERR_STATE, "in-process recv: rank " + std::to_string(peer) + " has not sent within " + std::to_string(wait_s) + " s (every rank must call er_gather_pass)");
-        auto it = s->box->slots.find(key);
-        msg = it->second;
-        s->box->slots.erase(it);
+        auto& q = s->box->slots[key];
+        msg = q.front();
+        q.pop_front();
     }
     int rc = ER_OK;
     if (msg.bytes != bytes) rc = fail(ER_ERR_STATE, "in-process recv: size mismatch (" + std::to_string(msg.bytes) + " sent, " + std::to_string(bytes) + " expected)");

@@ -372,8 +372,7 @@ private:
         std::vector<float> img;
         const bool want_denoise = parsePass(pass) == ER_PASS_DENOISE || (rm.pars.denoise && parsePass(pass) == ER_PASS_BEAUTY);
         if (want_denoise) {
-            rm.denoise();                               // fills the DENOISE plane from the current BEAUTY + NORMAL planes
-            img = rm.get_pass("denoise");
+            img = rm.get_denoised();                    // gathers, fills the DENOISE plane from the current BEAUTY + NORMAL planes and reads it: one step against the render thread
             for (size_t i = 3; i < img.size(); i += 4) img[i] = 1.0f;   // :270-272
         } else {
             img = rm.get_pass(pass);

@@ -14,6 +14,7 @@
 // Only what the per-sample path consumes is mirrored (OBJ ingest: eleven_obj.hpp beside this file; denoise(): the
 // library's own filter in place of DenoiseManager's OIDN call); commands and TCP stay the reference's.  Errors surface as std::runtime_error carrying er_last_error(); nothing falls back to the CPU.
 #pragma once
+#include <mutex>
 #include <thread>
 #include <algorithm>
 #include <cctype>
@@ -260,27 +261,41 @@ public:
             }
         }
     }
-    // body of kernel_render_enqueue's loop: n more samples on every rank (the launches go out side by side, then the waits)
+    // body of kernel_render_enqueue's loop: n more samples on every rank (the launches go out side by side, then the waits).
+    // With several ranks a read-back is a SEQUENCE of library calls (gathers, denoise, read) that must see one frame: if the
+    // render thread enqueued samples on rank 0 between the gathers and er_denoise, the library would refuse the denoise
+    // (its gathered planes are stale, ER_ERR_STATE) and the tiles of a preview would mix sample counts.  frame_mtx_
+    // makes render() and such a sequence take turns; the render thread sizes its calls to about 50 ms, so a read-back waits
+    // that long at most.  One rank needs none of this: er_read_pass is a sample-boundary snapshot by itself.
     void render(unsigned n_samples) {
+        std::unique_lock<std::mutex> lk(frame_mtx_, std::defer_lock);
+        if (ers_.size() > 1) lk.lock();
         std::string err;
         for (ErScene* e : ers_) if (er_render_samples_async(e, n_samples) != ER_OK && err.empty()) err = er_last_error();
         for (ErScene* e : ers_) if (er_wait(e, nullptr) != ER_OK && err.empty()) err = er_last_error();
         if (!err.empty()) throw std::runtime_error(err);
     }
     std::vector<float> get_pass(const std::string& pass) {   // src/Managers.cpp:287-302
-        std::vector<float> out((size_t)pars.width * pars.height * 4);
         if (ers_.empty()) throw std::runtime_error("get_pass: no render has been started");
-        gather(parsePass(pass));
-        check(er_read_pass(ers_[0], parsePass(pass), out.data()));
-        return out;
+        std::unique_lock<std::mutex> lk(frame_mtx_, std::defer_lock);
+        if (ers_.size() > 1) lk.lock();
+        return get_pass_unlocked(parsePass(pass));
     }
     // DenoiseManager::denoise (src/Managers.cpp:319-343) called OIDN on the host; here the device fills the DENOISE plane --
     // on a sharded frame on rank 0, after BEAUTY and NORMAL have been gathered there
     void denoise(unsigned levels = 0, float colour_sigma = 0) {
         if (ers_.empty()) throw std::runtime_error("denoise: no render has been started");
-        gather(ER_PASS_BEAUTY);
-        gather(ER_PASS_NORMAL);
-        check(er_denoise(ers_[0], levels, colour_sigma));
+        std::unique_lock<std::mutex> lk(frame_mtx_, std::defer_lock);
+        if (ers_.size() > 1) lk.lock();
+        denoise_unlocked(levels, colour_sigma);
+    }
+    // denoise + read of the DENOISE plane as ONE step against the render thread (get_pass denoise / `denoise: true`)
+    std::vector<float> get_denoised(unsigned levels = 0, float colour_sigma = 0) {
+        if (ers_.empty()) throw std::runtime_error("denoise: no render has been started");
+        std::unique_lock<std::mutex> lk(frame_mtx_, std::defer_lock);
+        if (ers_.size() > 1) lk.lock();
+        denoise_unlocked(levels, colour_sigma);
+        return get_pass_unlocked(ER_PASS_DENOISE);
     }
     RenderInfo get_render_info() {   // src/Managers.cpp:211-232; several ranks: the one that is furthest behind
         RenderInfo i;
@@ -298,6 +313,18 @@ public:
 private:
     std::vector<ErScene*> ers_;
     std::vector<ErComm*> comms_;
+    std::mutex frame_mtx_;
+    std::vector<float> get_pass_unlocked(int pass) {
+        std::vector<float> out((size_t)pars.width * pars.height * 4);
+        gather(pass);
+        check(er_read_pass(ers_[0], pass, out.data()));
+        return out;
+    }
+    void denoise_unlocked(unsigned levels, float colour_sigma) {
+        gather(ER_PASS_BEAUTY);
+        gather(ER_PASS_NORMAL);
+        check(er_denoise(ers_[0], levels, colour_sigma));
+    }
     static void check(int rc, const char* what = nullptr) { if (rc != ER_OK) throw std::runtime_error(what ? what : er_last_error()); }
     // every rank's owned pixels of one plane -> rank 0's plane: one er_gather_pass per rank, side by side (the RCCL sends block until
     // the root has posted its receives, so the ranks cannot take turns on one thread)

@@ -170,12 +170,15 @@ def torture(n_tris=1_000_000, x_res=1920, y_res=1080, seed=12345, n_materials=64
 
 
 def blob_instances(n_instances=10000, tris_per_blob=1000, x_res=3840, y_res=2160, seed=12345, grid=(25, 20, 20), spacing=0.1):
-    """C4: instances of a ~1000-triangle smooth blob (subdivided octahedron with radial noise, SMOOTH vertex
+    """C4: instances of a 1000-triangle smooth blob (subdivided octahedron with radial noise, SMOOTH vertex
     normals) flattened into world-space triangles on a jittered grid (the reference has no instancing:
     MeshObject is a triangle range, src/MeshObject.hpp:14-22)."""
-    # unit blob: octahedron with every face cut into f x f triangles (8 f^2 faces, f chosen nearest to tris_per_blob:
-    # 968 for 1000), vertices pushed onto the unit sphere and shared between faces so the normals come out smooth
-    f = max(1, int(round(np.sqrt(max(tris_per_blob, 8) / 8.0))))
+    # unit blob: octahedron with every face cut into f x f triangles (8 f^2 faces, the largest f with 8 f^2 <= tris_per_blob:
+    # 968 for 1000), vertices pushed onto the unit sphere and shared between faces so the normals come out smooth; the
+    # remaining (tris_per_blob - 8 f^2) / 2 pairs of triangles come from splitting that many edges at their midpoints (a split
+    # edge turns its two triangles into four: +2), edges spread evenly over the face list and no triangle split twice --
+    # 16 splits make the 1 000 triangles of BASELINE config 4 exactly, the mesh stays closed and welded
+    f = max(1, int(np.floor(np.sqrt(max(tris_per_blob, 8) / 8.0))))
     octa = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float64)
     octa_faces = [[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]]
     pts, tri = [], []
@@ -196,6 +199,45 @@ def blob_instances(n_instances=10000, tris_per_blob=1000, x_res=3840, y_res=2160
     _, first, inverse = np.unique(np.round(pts, 9), axis=0, return_index=True, return_inverse=True)
     verts = pts[first]
     faces = inverse.reshape(-1)[np.array(tri, np.int64)]
+    n_split = max(0, (tris_per_blob - len(faces)) // 2)
+    if n_split:
+        faces = [list(map(int, t)) for t in faces]
+        edge_faces = {}
+        for fi, t in enumerate(faces):
+            for k in range(3):
+                edge_faces.setdefault((min(t[k], t[(k + 1) % 3]), max(t[k], t[(k + 1) % 3])), []).append(fi)
+        used, extra_verts, done = set(), [], 0
+        n_faces0 = len(faces)
+        for fi in ((k * n_faces0) // n_split for k in range(n_split)):
+            # the first face at or after fi with an edge whose two triangles are both still whole
+            for fj in list(range(fi, n_faces0)) + list(range(0, fi)):
+                if fj in used:
+                    continue
+                t = faces[fj]
+                pick = None
+                for k in range(3):
+                    a, b = t[k], t[(k + 1) % 3]
+                    other = [g for g in edge_faces[(min(a, b), max(a, b))] if g != fj]
+                    if len(other) == 1 and other[0] not in used:
+                        pick = (a, b, t[(k + 2) % 3], other[0])
+                        break
+                if pick:
+                    break
+            a, b, c, fo = pick
+            m = verts[a] + verts[b]
+            extra_verts.append(m / np.linalg.norm(m))
+            mi = len(verts) + len(extra_verts) - 1
+            to = faces[fo]
+            ko = [k for k in range(3) if to[k] == b and to[(k + 1) % 3] == a][0]     # the neighbour runs the edge the other way
+            d = to[(ko + 2) % 3]
+            faces[fj] = [a, mi, c]
+            faces.append([mi, b, c])
+            faces[fo] = [b, mi, d]
+            faces.append([mi, a, d])
+            used.update((fj, fo))
+            done += 1
+        verts = np.concatenate([verts, np.array(extra_verts, np.float64)])
+        faces = np.array(faces, np.int64)
     bump = 1.0 + 0.15 * np.sin(5 * verts[:, 0]) * np.sin(4 * verts[:, 1] + 1.0) * np.sin(3 * verts[:, 2] + 2.0)
     verts = verts * bump[:, None]
     # smooth vertex normals: area-weighted face normals

@@ -82,3 +82,24 @@ def test_gloo_framebuffer_gather(world, res):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok and red == 1.0 for (_, ok, red) in results), results
+
+
+def test_bench_gpus_n_starts_its_own_n_ranks():
+    """`python3 bench.py --gpus 2` with no launcher around it must become TWO ranks (it used to render the whole
+    frame on one GPU and print n_gpus 1).  ER_BENCH_DRY_RUN=1: the ranks join over gloo and rank 0 reports who is there --
+    nothing touches a GPU, so this runs here.  Under a launcher (WORLD_SIZE set) the same file must NOT start ranks again."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ER_BENCH_DRY_RUN"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3"], env=env, capture_output=True, text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.stdout[-1500:], p.stderr[-1500:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_joined"] == [0, 1]
+    assert "torch.distributed.run" in p.stderr and "--nproc-per-node=2" in p.stderr
+    # one rank, no launcher: no child process
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["n_gpus"] == 1 and "torch.distributed.run" not in p.stderr

@@ -37,3 +37,20 @@ def test_a_failed_default_schedule_is_reported_as_degraded_and_exits_nonzero():
     assert line["degraded"] is True
     assert "simulated failure" in line["config"]["schedule_fallback"]
     assert line["config"]["schedule"] == "wavefront" and line["value"] > 0
+
+
+def test_bench_gpus_2_without_a_launcher_runs_two_ranks():
+    """`python3 bench.py --gpus 2` as the driver types it: the file starts its own two ranks (child process), each renders its
+    tiles, the planes are gathered to rank 0.  On this one-GPU box the two ranks share GPU 0 and talk over gloo
+    (ER_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device) -- the control flow, the sharding and the line are the real ones."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["ER_BENCH_REHEARSAL"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, (p.stdout[-2000:], p.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2
+    assert len(line["ranks"]["kernel_ms"]) == 2 and len(line["ranks"]["paths"]) == 2
+    assert sum(line["ranks"]["paths"]) == 256 * 192 * 3           # the two shares make the frame, once
+    assert line["gather"] and "gloo" in line["gather"]
+    assert line["config"]["sharding"].endswith("% 2") and line["scaling"] == "strong"

@@ -7,10 +7,6 @@ A one-GPU box cannot run RCCL with more than one rank (RCCL refuses two ranks on
     size 1.  The N-GPU run is bench.py --gpus N, which the driver launches on a whole node.
 """
 import ctypes as C
-import os
-
-os.environ.setdefault("ER_LOCAL_RECV_TIMEOUT_S", "2")      # (read once by the library: how long an in-process receive waits for its send)
-
 import numpy as np
 import pytest
 
@@ -21,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("sched", [0, abi.FLAG_WAVEFRONT, abi.FLAG_STREAM])
-def test_gather_pass_over_the_loopback_transport_reassembles_the_frame(sched):
+def test_gather_pass_over_the_loopback_transport_reassembles_the_frame(sched, monkeypatch):
     lib = abi.load()
     sc = scenes.soup(5000, 100, 76, seed=9, hdri_size=(64, 32))     # 100x76: partial tiles on both edges
     full = gpu_render(sc, 5, max_bounces=8, flags=sched)
@@ -56,11 +52,42 @@ def test_gather_pass_over_the_loopback_transport_reassembles_the_frame(sched):
     # a non-root rank still holds only its own pixels
     other = rms[0].get_pass("beauty")
     assert (other.view(np.uint32) != full["beauty"].view(np.uint32)).any()
-    # the root before its peers have sent: a state error, not a hang
+    # the root before its peers have sent: a state error, not a hang (the in-process receive's timeout, shortened for this
+    # ONE call only: the library reads the variable per call, every other test keeps the 120 s default)
+    monkeypatch.setenv("ER_LOCAL_RECV_TIMEOUT_S", "2")
     assert lib.er_gather_pass(rms[root].handle, 0, comms[root], root) == abi.ER_ERR_STATE
     assert b"has not sent within" in lib.er_last_error()
+    monkeypatch.delenv("ER_LOCAL_RECV_TIMEOUT_S")
     # rank / world of scene and communicator must match
     assert lib.er_gather_pass(rms[0].handle, 0, comms[2], root) == abi.ER_ERR_INVALID_ARG
+    for rm in rms:
+        rm.close()
+    for c in comms:
+        lib.er_comm_destroy(c)
+
+
+def test_in_process_transport_is_a_fifo_two_passes_sent_before_the_first_receive():
+    """a non-root rank that gathers pass A and then pass B before the root has received A must not lose A (one
+    mailbox slot per (src, dst) used to free A as "an unclaimed older message": the root's gather of A then received B's
+    pixels, sizes being equal, and its gather of B timed out)."""
+    lib = abi.load()
+    sc = scenes.soup(3000, 72, 56, seed=17, hdri_size=(64, 32))
+    full = gpu_render(sc, 4, max_bounces=8)
+    world, root = 2, 0
+    comms = (C.c_void_p * world)()
+    abi.check(lib.er_debug_comm_create_local(world, comms))
+    rms = []
+    for r in range(world):
+        rm = render.RenderingManager(render.RenderParameters(max_bounces=8, rank=r, world=world))
+        rm.start_rendering(sc)
+        rm.render(4)
+        rms.append(rm)
+    for p in (abi.PASS_BEAUTY, abi.PASS_NORMAL):          # rank 1 sends both planes ...
+        abi.check(lib.er_gather_pass(rms[1].handle, p, comms[1], root))
+    for p in (abi.PASS_BEAUTY, abi.PASS_NORMAL):          # ... before the root receives the first
+        abi.check(lib.er_gather_pass(rms[root].handle, p, comms[root], root))
+    for name in ("beauty", "normal"):
+        assert (rms[root].get_pass(name).view(np.uint32) == full[name].view(np.uint32)).all(), name
     for rm in rms:
         rm.close()
     for c in comms:

@@ -360,11 +360,11 @@ def test_c5_full_size_properties():
 
 
 def test_c4_full_size_properties():
-    """BASELINE config 4 at full size: 9.68M triangles (10 000 instances of a 968-triangle smooth-normal blob), 3840x2160.
+    """BASELINE config 4 at full size: 10M triangles (10 000 instances of a 1 000-triangle smooth-normal blob), 3840x2160.
     Whole frame once (finite, clamped, every path counted, sample plane = calls + 1), then the three schedules bit for
     bit on a window of tiles, which must also equal the whole-frame render on the pixels it owns."""
     sc = scenes.blob_instances()
-    assert sc.tri_count == 9_680_000 and (sc.x_res, sc.y_res) == (3840, 2160)
+    assert sc.tri_count == 10_000_000 and (sc.x_res, sc.y_res) == (3840, 2160)
     a = gpu_render(sc, 2, max_bounces=8)
     assert a["counters"]["paths"] == 3840 * 2160 * 2
     assert (a["samples"] == 3).mean() > 0.999
@@ -433,3 +433,30 @@ def test_read_back_during_asynchronous_rendering_is_a_sample_boundary_snapshot(f
     rm.close()
     assert (got3.view(np.uint32) == want3["beauty"].view(np.uint32)).all()
     assert (got8.view(np.uint32) == want8["beauty"].view(np.uint32)).all()
+
+
+def test_two_threads_reading_two_passes_of_one_scene_each_get_their_own():
+    """er_read_pass gathers the requested plane into the scene's ONE staging buffer and then copies it out; with
+    the lock released in between, two threads could interleave as gather A, gather B, copy, copy and the first silently
+    received the other pass.  The lock now spans gather + copy: 40 concurrent pairs of reads, every one its own plane."""
+    import threading
+    sc = scenes.soup(20000, 320, 200, seed=23, hdri_size=(128, 64))
+    rm = render.RenderingManager(render.RenderParameters(max_bounces=8))
+    rm.start_rendering(sc)
+    rm.render(3)
+    want = {p: rm.get_pass(p) for p in ("beauty", "normal")}
+    assert (want["beauty"].view(np.uint32) != want["normal"].view(np.uint32)).any()
+    wrong = []
+
+    def reader(name):
+        for _ in range(40):
+            got = rm.get_pass(name)            # ctypes releases the GIL for the call
+            if not (got.view(np.uint32) == want[name].view(np.uint32)).all():
+                wrong.append(name)
+    threads = [threading.Thread(target=reader, args=(n,)) for n in ("beauty", "normal")]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    rm.close()
+    assert not wrong, wrong

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One table per rocprofv3 --pmc pass directory set (tools/pmc_stream.sh, tools/pmc_pool.sh): the counters of one kernel summed
+"""One table per rocprofv3 --pmc pass directory set (tools/pmc_passes.sh): the counters of one kernel summed
 over its launches, with the ratios DESIGN.md quotes.  SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles
 (MI355X_MICROARCH.md); a wave is, at any time, issuing (ACTIVE_INST_ANY), stalled at issue (WAIT_INST_ANY) or parked in a wait
 (WAIT_ANY).
@@ -72,7 +72,7 @@ def main():
         if g("tcp_stall", c) is not None and ga:
             # GRBM_GUI_ACTIVE sums the 8 XCDs; the TCP counters sum the 256 CUs
             ratio(f"{c} per CU / kernel cycles", g("tcp_stall", c) / 256.0, ga / 8.0)
-    # vector-memory front end (tools/pmc_ta.sh): *_sum counters add the 256 CUs, GRBM_GUI_ACTIVE adds the 8 XCDs
+    # vector-memory front end (the ta*/tcp*/td* passes of tools/pmc_passes.sh): *_sum counters add the 256 CUs, GRBM_GUI_ACTIVE adds the 8 XCDs
     def per_cu_cycle(p, c):
         return (g(p, c) / 256.0, (g(p, "GRBM_GUI_ACTIVE") or 0) / 8.0) if g(p, c) is not None else (None, None)
     for label, p, c in (("TA busy   (TA_TA_BUSY per CU / kernel cycles)", "ta1", "TA_TA_BUSY_sum"),
@@ -88,6 +88,11 @@ def main():
     ratio("L1 miss share   (TCP_TCC_READ_REQ / TCP_TOTAL_CACHE_ACCESSES)", g("tcp2", "TCP_TCC_READ_REQ_sum"), g("tcp2", "TCP_TOTAL_CACHE_ACCESSES_sum"))
     ratio("L2 read latency seen by the TCP, cycles   (TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ)", g("tcp3", "TCP_TCC_READ_REQ_LATENCY_sum"), g("tcp2", "TCP_TCC_READ_REQ_sum"), fmt="{:.0f}")
     ratio("time of a wave-instruction in the TCP, cycles   (TCP_TCP_LATENCY / TCP_TA_TCP_STATE_READ)", g("tcp3", "TCP_TCP_LATENCY_sum"), g("tcp3", "TCP_TA_TCP_STATE_READ_sum"), fmt="{:.0f}")
+    for label, p, c in (("TD busy   (TD_TD_BUSY per CU / kernel cycles)", "td1", "TD_TD_BUSY_sum"),
+                        ("TD stalled by the TCP / kernel cycles", "td1", "TD_TC_STALL_sum")):
+        a, b = per_cu_cycle(p, c)
+        ratio(label, a, b)
+    ratio("TD busy cycles per load wave-instruction", g("td2", "TD_TD_BUSY_sum"), g("td2", "TD_LOAD_WAVEFRONT_sum"), fmt="{:.1f}")
     ratio("LDS bank-conflict cycles / LDS active cycles", g("lds", "SQ_LDS_BANK_CONFLICT"), g("lds", "SQ_LDS_IDX_ACTIVE"))
     f, w = g("fetch", "FETCH_SIZE"), g("write", "WRITE_SIZE")
     if f is not None and w is not None:
