@@ -859,6 +859,7 @@ void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lig
     }();
     if (S.owned_tile_count == 0 || n_samples == 0) return;
     if (tracers > ST_MAX_TRACERS) tracers = ST_MAX_TRACERS;      // (the LDS traversal stacks are sized for that many; at least 3 shader waves stay)
+    if (tracers > ST_THREADS / 64u - 1u) tracers = ST_THREADS / 64u - 1u;      // (a build with fewer waves per CU, -DST_THREADS=512: at least one shader wave)
     if (tracers < 1u) tracers = 1u;
     const bool ext = er_ext_active(S);
     auto k = count ? (ext ? er_stream_kernel<true, true> : er_stream_kernel<true, false>) : (ext ? er_stream_kernel<false, true> : er_stream_kernel<false, false>);

@@ -2,7 +2,7 @@
 """Where a shader wave of the streaming schedule spends its time, by section of the shading step.
 
 Needs the diagnostic build:  make -C elevenrender_amd/csrc BUILD=build_tp OUT=../libeleven_tp.so EXTRA=-DER_TIME_PROBE
-and runs on the GPU box:     ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_tp.so python3 tools/shader_sections.py [C2|C5]
+and runs on the GPU box:     ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_tp.so python3 tools/shader_sections.py [C2|C4|C5] [passes]
 In that build the shader waves stamp s_memtime at section boundaries (ER_TPS / ER_TP in er_stream.hip, er_bounce.inc) and the
 event counters carry the summed cycles / 16 per section instead of events."""
 import os
@@ -24,6 +24,8 @@ def main():
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     if cfg == "C5":
         sc, mb, fl = scenes.torture(1_000_000, 1920, 1080, seed=12345), 16, abi.FLAG_POINT_LIGHTS | abi.FLAG_MIS
+    elif cfg == "C4":
+        sc, mb, fl = scenes.blob_instances(), 8, 0
     else:
         sc, mb, fl = scenes.soup(1_000_000, 1920, 1080, seed=12345), 8, 0
     rm = render.RenderingManager(render.RenderParameters(max_bounces=mb, flags=abi.FLAG_STREAM | abi.FLAG_COUNTERS | fl))
@@ -35,7 +37,7 @@ def main():
     rm_info = {"cus": render.list_devices()[0]["max_compute_units"]}
     rm.close()
     tot = sum(c[k] for k in KEYS)
-    tracers = int(os.environ.get("ER_STREAM_TRACERS", "10"))
+    tracers = int(os.environ.get("ER_STREAM_TRACERS", "11" if cfg == "C5" else "12"))
     info = rm_info
     cus = info["cus"]
     steps, slots, tr_cyc = c["paths"], c["bounce_samples"], c["rays"] * 16

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Round-4 knob sweeps on the GPU box (one process at a time, each under its own timeout; stops at the first failure).
+#   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU, fused schedule
+#   bash tools/sweep_r04.sh c4     -> C4: tracer/shader split, ring-visit and batch thresholds
+set -o pipefail
+what=${1:?sim8|c4}
+out=gpurun_out/sweep_r04_$what
+mkdir -p $out
+line() { python3 -c "
+import json,sys
+d=json.loads(open('$1').read().strip().splitlines()[-1]); r=d['roofline']
+print('$2', d['value'], 'Msamples/s', d['ms_per_step'], 'ms/step', 'lanes', (r.get('trace_lanes') or {}).get('busy'), d['config']['schedule'])
+"; }
+run() {  # name, env assignments..., -- bench args
+  name=$1; shift
+  envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  if ! env "${envs[@]}" timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-trace-phase "$@" > $out/$name.log 2> $out/$name.err; then echo "$name FAILED"; tail -n 5 $out/$name.err; exit 1; fi
+  line $out/$name.log "$name ${envs[*]}"
+}
+if [ "$what" = sim8 ]; then
+  S="--sim-world 8 --steps 20 --warmup 5"
+  for t in 6 8 10 11 12 13; do run w16_t$t ER_STREAM_TRACERS=$t -- $S; done
+  for t in 6 8 9 10; do run w12_t$t ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_w12.so ER_STREAM_TRACERS=$t -- $S; done
+  for t in 4 5 6; do run w8_t$t ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_w8.so ER_STREAM_TRACERS=$t -- $S; done
+  run fused X=1 -- $S --schedule fused
+  run w16_t12_batch16 ER_STREAM_TRACERS=12 ER_STREAM_BATCH_MIN=16 ER_STREAM_FIN_MIN=16 -- $S
+  run w12_t9_batch16 ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_w12.so ER_STREAM_TRACERS=9 ER_STREAM_BATCH_MIN=16 ER_STREAM_FIN_MIN=16 -- $S
+else
+  S="--config C4 --steps 6 --warmup 1"
+  for t in 10 11 12 13; do run t$t ER_STREAM_TRACERS=$t -- $S; done
+  run t12_refill4 ER_STREAM_TRACERS=12 ER_STREAM_REFILL_MIN=4 -- $S
+  run t12_refill24 ER_STREAM_TRACERS=12 ER_STREAM_REFILL_MIN=24 -- $S
+  run t11_batch48 ER_STREAM_TRACERS=11 ER_STREAM_BATCH_MIN=48 ER_STREAM_FIN_MIN=48 -- $S
+fi
