@@ -326,6 +326,16 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         // er_stream.hip); before: 11 + 5, round 2: 10 + 6.  With the point-light extension a shading step is a third longer (a second
         // BRDF evaluation, a second shadow query): 11 + 5 there (C5: 1 188 vs 1 130 Msamples/s, profiles/r03_ab_split_by_config.log)
         s->stream_tracers = lights_on ? 11 : 12;
+        // A workgroup that owns hardly more pixels than it has slots (an eighth of a 1080p frame: 1 012 pixels per CU) cannot fill 12 tracer
+        // waves -- a pixel's samples are one RNG stream, so pixels in flight are all the parallelism there is -- and runs faster as 9 tracer +
+        // 3 shader waves of 168 registers (the shading step then spills 34 registers instead of 111 and three shader waves serve what four
+        // did): 1.23 vs 1.35 ms per pass at 1/8 (1 012 pixels per CU); at 1/6 (1 350 pixels) 16 waves are ahead again, 1.43 vs 1.47 (profiles/r04_sweep_small_shares.log)
+        s->stream_waves = 16;
+        {
+            const size_t px_per_cu = owned.size() * 64 / std::max<uint32_t>(1u, s->stream_blocks);
+            if (px_per_cu <= ER_STREAM_SMALL_SHARE) { s->stream_waves = 12; s->stream_tracers = lights_on ? 8 : 9; }
+        }
+        if (const char* e = getenv("ER_STREAM_WAVES")) { s->stream_waves = atoi(e) == 12 ? 12 : 16; s->stream_tracers = s->stream_waves == 12 ? (lights_on ? 8 : 9) : (lights_on ? 11 : 12); }   // A/B knob
         if (const char* e = getenv("ER_STREAM_TRACERS")) s->stream_tracers = (uint32_t)std::min(13, std::max(1, atoi(e)));   // tuning knob
         const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
         if ((rc = upload(s->d_wf4, nullptr, slots * er_stream_record_bytes(lights_on) / sizeof(float4), s->stream)) != ER_OK) return rc;
@@ -500,7 +510,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
         er_launch_fused(s->dev, s->d_ticket.p, s->d_spill.p, n, count, s->fused_blocks, s->stream);
     } else if (s->params.flags & ER_FLAG_STREAM) {
         er_launch_stream(s->dev, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_deal.p, (uint32_t)s->d_deal.n, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
-                         s->stream_blocks, s->stream_tracers, s->stream);
+                         s->stream_blocks, s->stream_tracers, s->stream_waves, s->stream);
     } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
         er_launch_render(s->dev, n, count, s->stream);
     }

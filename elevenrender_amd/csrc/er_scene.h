@@ -181,7 +181,7 @@ struct ErScene {
     DevBuf<uint2> d_spill;
     DevBuf<uint32_t> d_guide, d_ticket, d_deal;      // d_deal: the streaming schedule's deal of tiles to workgroups (er_stream_deal_tiles)
     uint32_t fused_blocks = 0;
-    uint32_t stream_blocks = 0, stream_tracers = 0, stream_ring_cap = 0;     // streaming schedule (er_stream.hip): workgroups; tracer waves of the 16
+    uint32_t stream_blocks = 0, stream_tracers = 0, stream_waves = 16, stream_ring_cap = 0;     // streaming schedule (er_stream.hip): workgroups; tracer waves of the 16
     bool stream_lights = false;                         //   slot records carry the point-light query's line
     uint32_t* stream_ctl = nullptr;                     //   [0] pixel ticket, [1] status word
     std::vector<WfState> wf;              // slot pools (see er_render_begin)

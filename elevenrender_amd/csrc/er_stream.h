@@ -15,15 +15,19 @@ struct WfState;
                                   // rings of more slots take is worth more as tree levels)
 #endif
 
+#ifndef ER_STREAM_SMALL_SHARE
+#define ER_STREAM_SMALL_SHARE 1152u  // owned pixels per CU up to which a workgroup runs as 12 waves of 168 registers (9 tracers + 3 shaders) instead of 16 of 128
+#endif
 #define ER_STREAM_MAX_RING 32768u  // cells of a workgroup's pixel ring at most (one "entry read" bit per cell in LDS): a rank may own
                                   // up to 256 x 32768 = 8.4 M pixels under this schedule (a 4K frame), beyond that er_render_begin takes the wavefront one
 
+// waves: 16 (1024 threads, 128 registers per wave) or 12 (768 threads, 168 registers) per workgroup, tracers of them trace.
 // records: slots * er_stream_record_bytes(lights) bytes (slots = blocks * ER_STREAM_SLOTS; lights: the scene uses the point-light
 // extension, whose queries take a third line per slot); spill: er_stream_spill_entries(blocks) uint2 entries; ring:
 // blocks * ring_cap uint2 entries (the workgroups' pixel rings; ring_cap = a power of two >= 64 * er_stream_deal_tiles(...) and
 // <= ER_STREAM_MAX_RING); status: one word, 0 unless a wave's watchdog or a ring guard fired.
 void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
-                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream);
+                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, hipStream_t stream);
 // the deal of the owned tiles to the workgroups (device copy of `out` = `deal` above, deal_count = out.size()); returns the most tiles of one workgroup
 uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, bool xcd_aware, std::vector<uint32_t>& out);
 uint32_t er_stream_record_bytes(bool lights);

@@ -100,9 +100,10 @@ static_assert((1u << ST_RQ_LOG2) >= ER_STREAM_SLOTS && (1u << ST_RQ_LOG2) >= 4u 
 #ifndef ER_TRACER_PRIO
 #define ER_TRACER_PRIO 0
 #endif
-#ifndef ST_THREADS
-#define ST_THREADS 1024          // 16 waves per CU: four per SIMD, 128 VGPRs each
-#endif
+// Waves per CU = a template argument of the kernel (its launch bound decides the register budget): 16 waves of 128 registers -- four per
+// SIMD, the shader step spills 111 of them -- or 12 waves of 168 registers (34 spilled), which is faster when a workgroup owns so few
+// pixels that the tracer lanes cannot be filled anyway (one GPU's eighth of a 1080p frame: 1.26 instead of 1.34 ms per pass,
+// profiles/r04_sweep_sim_world8.log); er_api.cpp chooses by owned pixels per CU.
 // north_star: "top BVH levels staged in LDS".  Every workgroup keeps the first wide nodes in LDS (the tree is stored
 // breadth-first: 585 = levels 0-3, 47 KB) and the tracer lanes whose node is one of them read it with ds_read_b128 instead of
 // five global loads: 9 of a ray's 21 node visits on C2.  Measured on C2 with the first tracer: 0 nodes 1240, 73 -> 1274,
@@ -266,7 +267,7 @@ __device__ __forceinline__ void st_write_result(const StState& W, uint32_t rec, 
 
 }  // namespace
 
-template <bool COUNT, bool EXT>
+template <bool COUNT, bool EXT, uint32_t ST_THREADS>
 __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StState W, const uint32_t* deal, uint32_t deal_count, uint2* ring_base, uint32_t ring_cap,
                                                           uint32_t* status, uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min, uint32_t fin_min) {
     constexpr uint32_t RQ_LOG2 = ST_RQ_LOG2, SLOTS = ER_STREAM_SLOTS, TOP_NODES = ER_STREAM_TOP_NODES;
@@ -277,13 +278,13 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
     __shared__ uint32_t s_pxbits[ST_PXBITS_WORDS];
     __shared__ __attribute__((aligned(8))) uint32_t s_rq_ctl[ER_RING_WORDS], s_sq_ctl[ER_RING_WORDS], s_px_ctl[ER_RING_WORDS], s_fq_ctl[ER_RING_WORDS];
     __shared__ uint32_t s_ctl[C_WORDS];
-    __shared__ float4 s_top[TOP_NODES * ER_NODE8_PIECES];
+    __shared__ float4 s_top[TOP_NODES * 5];          // (the LDS copy stays compact -- five pieces per node -- whatever the stride in device memory)
 #ifdef ER_TIME_PROBE
     __shared__ uint32_t s_tp[13];      // [1..9] cycles / 16 per section of the shader loop, [10] shader steps, [11] slots shaded, [12] cycles / 16 of tracer iterations
     if (threadIdx.x < 13) s_tp[threadIdx.x] = 0;
 #endif
-    for (uint32_t i = threadIdx.x; i < TOP_NODES * ER_NODE8_PIECES; i += ST_THREADS)
-        s_top[i] = i < S.node8_count * ER_NODE8_PIECES ? S.nodes8[i] : make_float4(0, 0, 0, 0);
+    for (uint32_t i = threadIdx.x; i < TOP_NODES * 5u; i += ST_THREADS)
+        s_top[i] = i / 5u < S.node8_count ? S.nodes8[(i / 5u) * ER_NODE8_PIECES + i % 5u] : make_float4(0, 0, 0, 0);
     const int lane = threadIdx.x & 63;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t g0 = blockIdx.x * SLOTS;          // this workgroup's first slot
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                     TravStep sg = st;
                     if (top) sg.node = false;          // (these lanes' node loads go to the shared dummy address)
                     trav_fetch(S, sg, D);
-                    if (top) { const float4* q = s_top + st.noff; D.n0 = q[0]; D.n1 = q[1]; D.n2 = q[2]; D.n3 = q[3]; D.n4 = q[4]; }
+                    if (top) { const float4* q = s_top + (ER_NODE8_PIECES == 5 ? st.noff : st.noff / (uint32_t)ER_NODE8_PIECES * 5u); D.n0 = q[0]; D.n1 = q[1]; D.n2 = q[2]; D.n3 = q[3]; D.n4 = q[4]; }
                 }
                 ER_MARK("tracer_apply");
                 bool occl = false;
@@ -805,7 +806,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
 hipError_t er_probe_stream(const char** which) {
     hipFuncAttributes a;
     *which = "er_stream_kernel";
-    return hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false>);
+    hipError_t e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 1024u>);
+    return e != hipSuccess ? e : hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 768u>);
 }
 
 // Which workgroup renders which tiles.  Workgroups b and b + 8 run on the same XCD and share its 4 MB L2 (observed dispatch
@@ -841,7 +843,7 @@ uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t ti
 }
 
 void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
-                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, hipStream_t stream) {
+                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, hipStream_t stream) {
     static const uint32_t refill_min = [] {
         const char* e = getenv("ER_STREAM_REFILL_MIN");
         int v = e ? atoi(e) : 12;
@@ -859,16 +861,19 @@ void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lig
     }();
     if (S.owned_tile_count == 0 || n_samples == 0) return;
     if (tracers > ST_MAX_TRACERS) tracers = ST_MAX_TRACERS;      // (the LDS traversal stacks are sized for that many; at least 3 shader waves stay)
-    if (tracers > ST_THREADS / 64u - 1u) tracers = ST_THREADS / 64u - 1u;      // (a build with fewer waves per CU, -DST_THREADS=512: at least one shader wave)
+    waves = waves == 12u ? 12u : 16u;
+    if (tracers > waves - 1u) tracers = waves - 1u;      // at least one shader wave
     if (tracers < 1u) tracers = 1u;
     const bool ext = er_ext_active(S);
-    auto k = count ? (ext ? er_stream_kernel<true, true> : er_stream_kernel<true, false>) : (ext ? er_stream_kernel<false, true> : er_stream_kernel<false, false>);
+    auto k16 = count ? (ext ? er_stream_kernel<true, true, 1024u> : er_stream_kernel<true, false, 1024u>) : (ext ? er_stream_kernel<false, true, 1024u> : er_stream_kernel<false, false, 1024u>);
+    auto k12 = count ? (ext ? er_stream_kernel<true, true, 768u> : er_stream_kernel<true, false, 768u>) : (ext ? er_stream_kernel<false, true, 768u> : er_stream_kernel<false, false, 768u>);
     StState st;
     st.base = (char*)records;
     st.spill = (uint2*)spill;
     st.slots = slots;
     st.stride = er_stream_record_bytes(lights);
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(ST_THREADS), 0, stream, S, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
+    if (waves == 12u) hipLaunchKernelGGL(k12, dim3(blocks), dim3(768), 0, stream, S, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
+    else hipLaunchKernelGGL(k16, dim3(blocks), dim3(1024), 0, stream, S, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
 }
 
 uint32_t er_stream_record_bytes(bool lights) { return lights ? ST_STRIDE_LIGHTS : ST_STRIDE_PLAIN; }

@@ -3,7 +3,7 @@
 #   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU, fused schedule
 #   bash tools/sweep_r04.sh c4     -> C4: tracer/shader split, ring-visit and batch thresholds
 set -o pipefail
-what=${1:?sim8|c4}
+what=${1:?sim8|c4|c4w|shares}
 out=gpurun_out/sweep_r04_$what
 mkdir -p $out
 line() { python3 -c "
@@ -25,10 +25,26 @@ if [ "$what" = sim8 ]; then
   run fused X=1 -- $S --schedule fused
   run w16_t12_batch16 ER_STREAM_TRACERS=12 ER_STREAM_BATCH_MIN=16 ER_STREAM_FIN_MIN=16 -- $S
   run w12_t9_batch16 ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_w12.so ER_STREAM_TRACERS=9 ER_STREAM_BATCH_MIN=16 ER_STREAM_FIN_MIN=16 -- $S
-else
+elif [ "$what" = c4 ]; then
   S="--config C4 --steps 6 --warmup 1"
   for t in 10 11 12 13; do run t$t ER_STREAM_TRACERS=$t -- $S; done
   run t12_refill4 ER_STREAM_TRACERS=12 ER_STREAM_REFILL_MIN=4 -- $S
   run t12_refill24 ER_STREAM_TRACERS=12 ER_STREAM_REFILL_MIN=24 -- $S
   run t11_batch48 ER_STREAM_TRACERS=11 ER_STREAM_BATCH_MIN=48 ER_STREAM_FIN_MIN=48 -- $S
+fi
+if [ "$what" = c4w ]; then      # (appended) C4 at 12 and 8 waves per CU: the shader step spills 34 / 0 registers instead of 111
+  S="--config C4 --steps 6 --warmup 1"
+  run w16_t12 ER_STREAM_TRACERS=12 -- $S
+  for t in 8 9; do run w12_t$t ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_w12.so ER_STREAM_TRACERS=$t -- $S; done
+  for t in 4 5; do run w8_t$t ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_w8.so ER_STREAM_TRACERS=$t -- $S; done
+fi
+if [ "$what" = shares ]; then      # one GPU's 1/2, 1/4, 1/8 share of the C2 frame at 16 and 12 waves per CU (ER_STREAM_WAVES)
+  for w in 2 3 4 6 8; do
+    S="--sim-world $w --steps 20 --warmup 5"
+    run s${w}_w16 ER_STREAM_WAVES=16 -- $S
+    run s${w}_w12 ER_STREAM_WAVES=12 -- $S
+  done
+  run s8_w12_t8 ER_STREAM_WAVES=12 ER_STREAM_TRACERS=8 -- --sim-world 8 --steps 20 --warmup 5
+  run s8_w12_t10 ER_STREAM_WAVES=12 ER_STREAM_TRACERS=10 -- --sim-world 8 --steps 20 --warmup 5
+  run s8_default X=1 -- --sim-world 8 --steps 20 --warmup 5
 fi
