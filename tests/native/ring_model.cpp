@@ -14,6 +14,10 @@
 //     variant 0  the protocol of the kernel
 //     variant 2  the same, but producers do NOT wait for the previous lap's reader (the protocol of round 2: plain overwrite) --
 //                a negative control: with small rings this loses rays or reads the wrong lap, and the model says so
+//   ring_model script
+//     the SAME negative control as ONE scripted interleaving on one thread (no timing in it): a reader is granted a position and
+//     stalls before reading its cell; the ring comes round; the checked producer of er_ring.h refuses to touch the cell until the
+//     reader has been, round 2's producer overwrites it and the stalled reader never finds its entry.  Exit code 0 = both seen.
 #include <atomic>
 #include <chrono>
 #include <cstdint>
@@ -360,7 +364,49 @@ struct Model {
 
 }  // namespace
 
+// The lapped-overwrite interleaving of round 2, forced: deterministic, single-threaded, on the ring functions themselves.
+static int scripted_negative_control() {
+    const uint32_t log2 = 2, cap = 1u << log2;
+    int failures = 0;
+    for (int checked = 1; checked >= 0; checked--) {
+        uint32_t cells[4] = {0, 0, 0, 0};
+        alignas(8) uint32_t ctl[ER_RING_WORDS] = {0, 0, 0, 0};
+        // lap 0: four entries written and published; a reader is granted position 0 and STALLS before it reads its cell
+        uint32_t base = er_ring_reserve(ctl, cap);
+        for (uint32_t i = 0; i < cap; i++)
+            if (!er_ring_put(cells, log2, base + i, 100u + i)) { printf("script: put of lap 0 failed\n"); failures++; }
+        er_ring_publish(ctl, cap);
+        uint32_t gbase = 0;
+        const uint32_t granted = er_ring_grant(ctl, 1u, gbase);
+        if (granted != 1u || gbase != 0u) { printf("script: unexpected grant\n"); failures++; }
+        // the ring comes round: a producer is handed position 4 = cell 0 of lap 1 while the reader of lap 0 has not been there
+        base = er_ring_reserve(ctl, 1u);
+        bool put_ok;
+        if (checked) {
+            put_ok = er_ring_put(cells, log2, base, 200u);        // must WAIT for the reader (here: until the guard expires)
+        } else {
+            er_ring_store(&cells[base & (cap - 1u)], er_ring_lap(base, log2) | ER_RING_FULL | 200u);      // round 2's producer
+            put_ok = true;
+        }
+        // now the stalled reader reads position 0
+        uint32_t payload = 0;
+        const bool got = er_ring_get(cells, log2, gbase, payload);
+        if (checked) {
+            const bool ok = !put_ok && got && payload == 100u;
+            printf("script: checked producer %s; the stalled reader then %s its entry (payload %u)\n", put_ok ? "OVERWROTE an unread cell" : "waited for the reader (guard)",
+                   got ? "found" : "LOST", payload);
+            if (!ok) failures++;
+        } else {
+            const bool ok = !got;      // the entry of lap 0 is gone: the reader waits for a cell state that can no longer come
+            printf("script: round 2's producer overwrote the unread cell; the stalled reader %s\n", got ? "still found an entry (payload of the wrong lap?)" : "never finds its entry (guard)");
+            if (!ok) failures++;
+        }
+    }
+    return failures ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && strcmp(argv[1], "script") == 0) return scripted_negative_control();
     Model m;
     m.n_slots = argc > 1 ? (uint32_t)atoi(argv[1]) : 8;
     m.n_pixels = argc > 2 ? (uint32_t)atoi(argv[2]) : 8;
