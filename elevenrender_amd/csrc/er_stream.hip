@@ -94,6 +94,9 @@ static_assert((1u << ST_RQ_LOG2) >= ER_STREAM_SLOTS && (1u << ST_RQ_LOG2) >= 4u 
 // since finished and escaped paths have batches of their own: 1 557 -> 1 627 Msamples/s, profiles/r03_ab_escaped_paths_to_finish_ring.log):
 // C2 1 367 -> 1 396, C5 983 -> 1 037, 4K 1 417 -> 1 435, 720p 1 283 -> 1 276 Msamples/s (profiles/r03_ab_wave_priority_*.log; at 10 + 6
 // the same priority LOSES 6 %: the tracers then wait for issue slots).  Tracer waves at priority 1 instead: +1 %.
+#ifndef ER_STREAM_SPLIT_WAIT
+#define ER_STREAM_SPLIT_WAIT 1   // 1: the tracer's triangle block runs while the node pieces are still arriving (er_trav.h trav_fetch_issue / trav_wait_*)
+#endif
 #ifndef ER_SHADER_PRIO
 #define ER_SHADER_PRIO 1         // s_setprio of the shader waves / of the tracer waves for their whole loops (0 = leave it)
 #endif
@@ -449,6 +452,31 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 TravData D;
                 ER_MARK("tracer_fetch");
                 const bool top = st.node && st.noff < (uint32_t)(TOP_NODES * ER_NODE8_PIECES);
+#if ER_STREAM_SPLIT_WAIT
+                bool occl = false;
+                {
+                    TravStep sg = st;
+                    if (top) sg.node = false;          // (these lanes' node loads go to the shared dummy address)
+                    TravRaw R;
+                    trav_fetch_issue(S, sg, R);
+                    trav_wait_tri(R, D);
+                    ER_MARK("tracer_apply");
+                    // the triangle block while the node pieces are still on their way
+                    const bool do_tri = busy && do_step;
+                    TravStep stt = st;
+                    stt.tri = st.tri && do_tri;
+                    occl = trav_apply_tri<COUNT>(T, S, stt, D, c_tris);
+                    trav_wait_node(R, D);
+                    if (top) { const float4* q = s_top + (ER_NODE8_PIECES == 5 ? st.noff : st.noff / (uint32_t)ER_NODE8_PIECES * 5u); D.n0 = q[0]; D.n1 = q[1]; D.n2 = q[2]; D.n3 = q[3]; D.n4 = q[4]; }
+                    TravStep sn = st;
+                    sn.node = st.node && do_tri && !occl;
+                    trav_apply_node<COUNT>(T, S, sn, D, c_nodes);
+                }
+                if (busy) {
+                    if (do_step && occl) finished = true;
+                    if (finished) { busy = false; done = true; done_occl = occl; }
+                }
+#else
                 {
                     TravStep sg = st;
                     if (top) sg.node = false;          // (these lanes' node loads go to the shared dummy address)
@@ -461,6 +489,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                     if (do_step && trav_apply<COUNT>(T, S, st, D, c_nodes, c_tris)) { occl = true; finished = true; }
                     if (finished) { busy = false; done = true; done_occl = occl; }
                 }
+#endif
 #ifdef ER_TIME_PROBE
                 if (lane == 0) atomicAdd(&s_tp[12], (unsigned)((__builtin_amdgcn_s_memtime() - tr0) >> 4));
 #endif

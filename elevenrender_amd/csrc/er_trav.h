@@ -153,6 +153,49 @@ ERD void trav_fetch(const DevScene& S, const TravStep& st, TravData& D) {
                  : "memory");
 }
 
+// The same fetch in three statements (streaming schedule, ER_STREAM_SPLIT_WAIT): the triangle pieces are requested FIRST and
+// waited for alone -- vector-memory operations return in issue order, so `vmcnt(5)` means "the six triangle loads have landed" --
+// and the triangle block runs while the five node pieces are still arriving; then `vmcnt(0)` and the node block.  Every
+// destination register is an in/out operand ("+v") of the statement that waits for it: that keeps all four components of a piece
+// live from its load to its wait, so the allocator can neither park another value in an unused component nor copy or spill a
+// register whose load has not landed (tools/check_split_wait.py reads the device assembly and fails the build check if any
+// instruction between a load and its wait names one of its destination registers).
+typedef float F4V __attribute__((ext_vector_type(4)));      // (a native vector: an in/out asm operand cannot be the float4 struct)
+struct TravRaw { F4V n0, n1, n2, n3, n4, a, b4, c, dd, e4, f4; };
+ERD float4 f4_of(F4V v) { return make_float4(v.x, v.y, v.z, v.w); }
+ERD void trav_fetch_issue(const DevScene& S, const TravStep& st, TravRaw& R) {
+    const float4* pn = S.nodes8 + (st.node ? st.noff : 0u);
+    const float4* pt = S.nodes8 + (st.tri ? st.toff : 0u);
+    const float4* pt2 = (st.tri && st.two) ? pt : S.nodes8;
+    asm volatile("; ER_SPLIT issue\n\t"
+                 "global_load_dwordx4 %5, %12, off\n\t"
+                 "global_load_dwordx4 %6, %12, off offset:16\n\t"
+                 "global_load_dwordx4 %7, %12, off offset:32\n\t"
+                 "global_load_dwordx4 %8, %13, off offset:48\n\t"
+                 "global_load_dwordx4 %9, %13, off offset:64\n\t"
+                 "global_load_dwordx4 %10, %13, off offset:80\n\t"
+                 "global_load_dwordx4 %0, %11, off\n\t"
+                 "global_load_dwordx4 %1, %11, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %11, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %11, off offset:48\n\t"
+                 "global_load_dwordx4 %4, %11, off offset:64"
+                 : "=&v"(R.n0), "=&v"(R.n1), "=&v"(R.n2), "=&v"(R.n3), "=&v"(R.n4), "=&v"(R.a), "=&v"(R.b4), "=&v"(R.c), "=&v"(R.dd),
+                   "=&v"(R.e4), "=&v"(R.f4)
+                 : "v"(pn), "v"(pt), "v"(pt2)
+                 : "memory");
+}
+ERD void trav_wait_tri(TravRaw& R, TravData& D) {
+    asm volatile("; ER_SPLIT wait_tri\n\ts_waitcnt vmcnt(5)"
+                 : "+v"(R.a), "+v"(R.b4), "+v"(R.c), "+v"(R.dd), "+v"(R.e4), "+v"(R.f4), "+v"(R.n0), "+v"(R.n1), "+v"(R.n2), "+v"(R.n3), "+v"(R.n4)
+                 :
+                 : "memory");
+    D.a = f4_of(R.a); D.b4 = f4_of(R.b4); D.c = f4_of(R.c); D.dd = f4_of(R.dd); D.e4 = f4_of(R.e4); D.f4 = f4_of(R.f4);
+}
+ERD void trav_wait_node(TravRaw& R, TravData& D) {
+    asm volatile("; ER_SPLIT wait_node\n\ts_waitcnt vmcnt(0)" : "+v"(R.n0), "+v"(R.n1), "+v"(R.n2), "+v"(R.n3), "+v"(R.n4) : : "memory");
+    D.n0 = f4_of(R.n0); D.n1 = f4_of(R.n1); D.n2 = f4_of(R.n2); D.n3 = f4_of(R.n3); D.n4 = f4_of(R.n4);
+}
+
 // phase 3, TRIANGLE part.  Returns true when a shadow query found a certain occluder (the ray is then complete).
 template <bool COUNT>
 ERD bool trav_apply_tri(Trav& T, const DevScene& S, const TravStep& st, const TravData& D, unsigned& c_tris) {

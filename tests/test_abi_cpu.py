@@ -197,3 +197,22 @@ def test_collective_entry_points_validate_without_a_gpu():
     if lib.er_device_count() == 0:       # a communicator needs a device; the failure is a status code with a text
         rc = lib.er_comm_create(ident, 0, 1, 0, C.byref(comm))
         assert rc in (abi.ER_ERR_NO_DEVICE, abi.ER_ERR_HIP) and lib.er_last_error()
+
+
+def test_no_instruction_touches_a_load_destination_between_its_issue_and_its_wait():
+    """The streaming kernel's traversal step issues its eleven loads in one asm statement and waits for them in two later ones
+    (csrc/er_trav.h trav_fetch_issue / trav_wait_tri / trav_wait_node: the triangle block runs while the node pieces arrive).  The
+    compiler does not know those loads are in flight, so a copy, spill or reuse of one of their destination registers in between
+    would be silent corruption on some waves of some launches.  tools/check_split_wait.py reads the device assembly the build
+    leaves beside the object (-save-temps=obj) and must find every site clean."""
+    import glob
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = glob.glob(os.path.join(root, "elevenrender_amd", "csrc", "build", "er_stream-hip-amdgcn-*gfx950.s"))
+    assert asm, "the build did not leave er_stream's device assembly (elevenrender_amd/csrc/Makefile: -save-temps=obj)"
+    so = os.path.join(root, "elevenrender_amd", "libeleven_hip.so")
+    assert os.path.getmtime(asm[0]) <= os.path.getmtime(so) + 1, "the assembly is newer than the library: rebuild"
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "check_split_wait.py"), asm[0]], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert "8 split-wait sites, 0 offending instructions" in p.stdout      # 4 instantiations x 2 wave counts
