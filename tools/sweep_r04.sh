@@ -3,7 +3,7 @@
 #   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU, fused schedule
 #   bash tools/sweep_r04.sh c4     -> C4: tracer/shader split, ring-visit and batch thresholds
 set -o pipefail
-what=${1:?sim8|c4|c4w|shares}
+what=${1:?sim8|c4|c4w|shares|knobs}
 out=gpurun_out/sweep_r04_$what
 mkdir -p $out
 line() { python3 -c "
@@ -47,4 +47,18 @@ if [ "$what" = shares ]; then      # one GPU's 1/2, 1/4, 1/8 share of the C2 fra
   run s8_w12_t8 ER_STREAM_WAVES=12 ER_STREAM_TRACERS=8 -- --sim-world 8 --steps 20 --warmup 5
   run s8_w12_t10 ER_STREAM_WAVES=12 ER_STREAM_TRACERS=10 -- --sim-world 8 --steps 20 --warmup 5
   run s8_default X=1 -- --sim-world 8 --steps 20 --warmup 5
+fi
+if [ "$what" = knobs ]; then      # C2 after the split wait: batch / refill thresholds again, shader-wave priority 2 and 3
+  S="--steps 20 --warmup 5"
+  run base X=1 -- $S
+  run batch48 ER_STREAM_BATCH_MIN=48 -- $S
+  run batch32 ER_STREAM_BATCH_MIN=32 -- $S
+  run fin32 ER_STREAM_FIN_MIN=32 -- $S
+  run fin48 ER_STREAM_FIN_MIN=48 -- $S
+  run refill8 ER_STREAM_REFILL_MIN=8 -- $S
+  run refill16 ER_STREAM_REFILL_MIN=16 -- $S
+  run refill20 ER_STREAM_REFILL_MIN=20 -- $S
+  run prio2 ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_p2.so -- $S
+  run prio3 ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_p3.so -- $S
+  run base2 X=1 -- $S
 fi
