@@ -325,6 +325,8 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         // 12 tracer + 4 shader waves (shader waves at issue priority 1; finished and escaped paths handled in batches of their own,
         // er_stream.hip); before: 11 + 5, round 2: 10 + 6.  With the point-light extension a shading step is a third longer (a second
         // BRDF evaluation, a second shadow query): 11 + 5 there (C5: 1 188 vs 1 130 Msamples/s, profiles/r03_ab_split_by_config.log)
+        // ... to begin with; after every completed call the split follows how full the tracer lanes were (er_stream_adapt: C4 settles at
+        // 11 + 5 after its first long call, C2 stays at 12 + 4)
         s->stream_tracers = lights_on ? 11 : 12;
         // A workgroup that owns hardly more pixels than it has slots (an eighth of a 1080p frame: 1 012 pixels per CU) cannot fill 12 tracer
         // waves -- a pixel's samples are one RNG stream, so pixels in flight are all the parallelism there is -- and runs faster as 9 tracer +
@@ -334,16 +336,21 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         {
             const size_t px_per_cu = owned.size() * 64 / std::max<uint32_t>(1u, s->stream_blocks);
             if (px_per_cu <= ER_STREAM_SMALL_SHARE) { s->stream_waves = 12; s->stream_tracers = lights_on ? 8 : 9; }
+            // the lane occupancy says something about the balance of the two roles only where pixels are plentiful: a share of a few
+            // pixels per slot cannot fill the lanes whatever the split (an eighth of a 1080p frame: 0.59 at the fastest split)
+            // (nor in the instrumented kernel of ER_FLAG_COUNTERS, whose slower tracer loop shifts the balance)
+            s->stream_adapt = px_per_cu >= 4u * ER_STREAM_SLOTS && !(p->flags & ER_FLAG_COUNTERS);
         }
         if (const char* e = getenv("ER_STREAM_WAVES")) { s->stream_waves = atoi(e) == 12 ? 12 : 16; s->stream_tracers = s->stream_waves == 12 ? (lights_on ? 8 : 9) : (lights_on ? 11 : 12); }   // A/B knob
-        if (const char* e = getenv("ER_STREAM_TRACERS")) s->stream_tracers = (uint32_t)std::min(13, std::max(1, atoi(e)));   // tuning knob
+        if (const char* e = getenv("ER_STREAM_TRACERS")) { s->stream_tracers = (uint32_t)std::min(13, std::max(1, atoi(e))); s->stream_adapt = false; }   // tuning knob: fixed split
+        if (const char* e = getenv("ER_STREAM_ADAPT")) s->stream_adapt = atoi(e) != 0;
         const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
         if ((rc = upload(s->d_wf4, nullptr, slots * er_stream_record_bytes(lights_on) / sizeof(float4), s->stream)) != ER_OK) return rc;
-        if ((rc = upload(s->d_wf1, nullptr, 2, s->stream)) != ER_OK) return rc;        // [1] status word
+        if ((rc = upload(s->d_wf1, nullptr, 6, s->stream)) != ER_OK) return rc;        // [1] status word, [2..5] the tracers' lane occupancy
         if ((rc = upload(s->d_spill, nullptr, er_stream_spill_entries(s->stream_blocks), s->stream)) != ER_OK) return rc;
         s->stream_ctl = s->d_wf1.p;
         s->stream_lights = lights_on;
-        HIP_TRY(hipMemsetAsync(s->stream_ctl, 0, 2 * sizeof(uint32_t), s->stream));
+        HIP_TRY(hipMemsetAsync(s->stream_ctl, 0, 6 * sizeof(uint32_t), s->stream));
         // the workgroups' pixel rings: (pixel, samples left) entries, one per pixel of the workgroup's share
         // (capacity rounded up to a power of two: positions are monotonic 32-bit counters and may wrap)
         // (no minimum beyond one tile: a producer that comes round to a cell whose entry has not been read yet waits for its
@@ -509,6 +516,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     if (s->params.flags & ER_FLAG_FUSED) {
         er_launch_fused(s->dev, s->d_ticket.p, s->d_spill.p, n, count, s->fused_blocks, s->stream);
     } else if (s->params.flags & ER_FLAG_STREAM) {
+        HIP_TRY(hipMemsetAsync(s->stream_ctl + 2, 0, 4 * sizeof(uint32_t), s->stream));      // the call's lane-occupancy counts
         er_launch_stream(s->dev, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_deal.p, (uint32_t)s->d_deal.n, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
                          s->stream_blocks, s->stream_tracers, s->stream_waves, s->stream);
     } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
@@ -576,11 +584,30 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
 // for a finished one.  The word stays set until the next er_render_begin.
 int er_scene_stream_status(ErScene* s, const char* who) {
     if (!(s->params.flags & ER_FLAG_STREAM) || !s->stream_ctl) return ER_OK;
-    uint32_t st[2] = {0, 0};
+    uint32_t st[6] = {0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpy(st, s->stream_ctl, sizeof(st), hipMemcpyDeviceToHost));
     if (st[1] != 0)
         return fail(ER_ERR_STATE, std::string(who) + ": the streaming schedule stopped without finishing (watchdog status " + std::to_string(st[1]) + "); the planes are incomplete");
+    const unsigned long long iters = (unsigned long long)st[2] | ((unsigned long long)st[3] << 32), busy = (unsigned long long)st[4] | ((unsigned long long)st[5] << 32);
+    s->stream_busy = iters ? (double)busy / (64.0 * (double)iters) : 0.0;
     return ER_OK;
+}
+
+// The two roles of the streaming kernel feed each other, and which one is short depends on the scene: how long a ray's traversal is
+// against how long its shading step is.  What the tracers' lanes say after a call (counted by the kernel itself, two scalar
+// operations per iteration): clearly not full = the shader waves cannot produce rays fast enough, and one tracer wave becomes a
+// shader wave for the next call.  Measured with the product kernel at 12 / 11 tracer waves (profiles/r04_adaptive_split.log): C2 0.90 /
+// 0.91 full, 12 + 4 faster by 4.5 %; C4 0.84 / 0.92, 11 + 5 faster by 3 %; C5 with lights 0.75 / 0.88, 11 + 5 faster by 5 %.  Lanes
+// that ARE full say nothing (C2 at 11 + 5 and C4 at 11 + 5 look alike), so the split only ever moves this way: one wave per completed
+// call while the lanes are under 0.86 full, down to 10 + 6 (7 + 5 of 12 waves).  The image does not depend on the split.
+static void er_stream_adapt(ErScene* s) {
+    static const bool verbose = getenv("ER_STREAM_VERBOSE") != nullptr;
+    if (verbose && (s->params.flags & ER_FLAG_STREAM) && !s->stream_adapt) fprintf(stderr, "[er_stream] tracer lanes %.3f full at %u + %u waves (fixed split)\n", s->stream_busy, s->stream_tracers, s->stream_waves - s->stream_tracers);
+    if (!s->stream_adapt || !(s->params.flags & ER_FLAG_STREAM) || s->stream_busy <= 0.0) return;
+    const uint32_t lo = s->stream_waves == 12 ? 7u : 10u;
+    const uint32_t before = s->stream_tracers;
+    if (s->stream_busy < 0.86 && s->stream_tracers > lo) s->stream_tracers--;
+    if (verbose) fprintf(stderr, "[er_stream] tracer lanes %.3f full at %u + %u waves -> %u + %u\n", s->stream_busy, before, s->stream_waves - before, s->stream_tracers, s->stream_waves - s->stream_tracers);
 }
 
 static int er_wait_impl(ErScene* s, float* elapsed_ms) {
@@ -599,6 +626,7 @@ static int er_wait_impl(ErScene* s, float* elapsed_ms) {
     }
     if (elapsed_ms) *elapsed_ms = ms;
     { int rc = er_scene_stream_status(s, "er_wait"); if (rc != ER_OK) { s->prof_used = 0; return rc; } }   // (the profiling window ends with the call either way)
+    er_stream_adapt(s);
     s->profile = ErProfile{};
     s->profile.schedule = s->params.flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM);
     s->profile.concurrency = (s->params.flags & ER_FLAG_WAVEFRONT) ? (uint32_t)std::max<size_t>(1, s->wf.size()) : 1u;

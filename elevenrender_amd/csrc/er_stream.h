@@ -25,7 +25,9 @@ struct WfState;
 // records: slots * er_stream_record_bytes(lights) bytes (slots = blocks * ER_STREAM_SLOTS; lights: the scene uses the point-light
 // extension, whose queries take a third line per slot); spill: er_stream_spill_entries(blocks) uint2 entries; ring:
 // blocks * ring_cap uint2 entries (the workgroups' pixel rings; ring_cap = a power of two >= 64 * er_stream_deal_tiles(...) and
-// <= ER_STREAM_MAX_RING); status: one word, 0 unless a wave's watchdog or a ring guard fired.
+// <= ER_STREAM_MAX_RING); status: five words at an address that is 4 (mod 8): [0] 0 unless a wave's watchdog or a ring guard fired,
+// [1..2] iterations of all tracer waves' loops and [3..4] the lanes that held a ray in them, both added up as 64-bit counts by the
+// launch (the caller zeroes them before it).
 void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
                       uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, hipStream_t stream);
 // the deal of the owned tiles to the workgroups (device copy of `out` = `deal` above, deal_count = out.size()); returns the most tiles of one workgroup

@@ -358,8 +358,10 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
 #if ER_TRACER_PRIO
             __builtin_amdgcn_s_setprio(ER_TRACER_PRIO);
 #endif
-            uint32_t ls = 0, kind = 0, rec = 0;   // the ray in hand: local slot, kind, index of its records (g, or g + W.slots)
+            uint32_t lsk = 0;      // the ray in hand: its ray-ring payload, local slot | kind << 11 (ONE register across the traversal; the
+                                   // record index g0 + slot (+ W.slots for a point-light query) is recomputed where it is needed)
             uint32_t idle = 0, progress = 0;
+            uint32_t a_iter = 0, a_busy = 0;      // iterations of this wave's loop and the lanes that held a ray in them (-> status[1..4])
             while (true) {
                 ER_MARK("tracer_loop_top");
                 // Every refill_min idle lanes the wave does its ring work in one go: FIRST the finished rays of the idle lanes are
@@ -372,7 +374,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 const bool visit = 64u - (unsigned)__popcll(bm0) >= refill_min || bm0 == 0;
                 if (visit && __ballot(done)) {
                     ER_MARK("tracer_publish");
-                    if (done) st_write_result(W, rec, T.shadow, done_occl, T.overflow, T.s0, T.s1);
+                    const uint32_t ls = lsk & ST_SLOT_MASK, kind = lsk >> ST_SLOT_BITS;
+                    if (done) st_write_result(W, g0 + ls + (kind == 2u ? W.slots : 0u), T.shadow, done_occl, T.overflow, T.s0, T.s1);
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     bool last = false;
                     uint32_t fin = 0;
@@ -405,9 +408,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         if (got) {
-                            ls = e & ST_SLOT_MASK;
-                            kind = e >> ST_SLOT_BITS;
-                            rec = g0 + ls + (kind == 2u ? W.slots : 0u);
+                            lsk = e;
+                            const uint32_t kind = e >> ST_SLOT_BITS;
+                            const uint32_t rec = g0 + (e & ST_SLOT_MASK) + (kind == 2u ? W.slots : 0u);
                             const bool shadow = kind != 0u;
                             const float4 ro = shadow ? W.sh_o(rec) : W.ray_o(rec);
                             const float4 rd = shadow ? W.sh_d(rec) : W.ray_d(rec);
@@ -432,6 +435,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                     continue;
                 }
                 idle = 0;
+                a_iter++;                                   // (wave-uniform: two scalar operations per iteration)
+                a_busy += (uint32_t)__popcll(bm);
 #ifdef ER_TIME_PROBE
                 const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -496,6 +501,12 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 ER_MARK("tracer_iter_end");
             }
             ER_MARK("tracer_loop_end");
+            // how full the tracer lanes were: the host reads it after the call and moves one wave between the two roles for the next
+            // call when the tracers starve or the shaders idle (er_api.cpp, er_stream_adapt)
+            if (lane == 0) {
+                atomicAdd((unsigned long long*)(status + 1), (unsigned long long)a_iter);
+                atomicAdd((unsigned long long*)(status + 3), (unsigned long long)a_busy);
+            }
         }
     }
     if (wave >= tracers) {
