@@ -1,19 +1,40 @@
 #!/bin/bash
-# Record run for profiles/: default bench line, rocprofv3 kernel statistics of the same command, and the HBM
-# traffic counters (separate --pmc passes, kernel trace only).  Run on the GPU box from the repo root:
-#   gpurun -- 'bash tools/record_run.sh r02 [bench args]'   then   python tools/make_profile_summary.py gpurun_out/record_r02 r02
+# Record run for profiles/ (one GPU box, repo root):   bash tools/record_run.sh r04
+#   1. the bench line as the driver types it (C2), and rocprofv3 --kernel-trace --stats of the same command;
+#   2. the other BASELINE scenes (C4, C5, C5 without the extensions, C1), one GPU's 1/2, 1/4, 1/8 share of the C2 frame, and the
+#      two-rank rehearsal of `bench.py --gpus 2` (no launcher around it: the file starts its own ranks);
+#   3. the PMC passes of the final kernel: C2 full set, C4 and C5 core set (tools/pmc_passes.sh; separate --pmc passes, kernel trace only).
+# Every step under its own timeout; the script stops at the first failure (no GPU step is started after a failed one).
+# Afterwards, in the build container:  python tools/pmc_traffic.py gpurun_out/pmc_<tag>_c2 <tag> C2  (and C4, C5),
+#   python tools/pmc_table.py gpurun_out/pmc_<tag>_c2 > profiles/<tag>_pmc_c2_stream_kernel.txt, and copy the logs.
 set -eo pipefail
-tag=${1:-r02}
-shift || true
-extra="$@"     # extra bench.py arguments for every run, e.g. --schedule wavefront
+tag=${1:-r04}
 out=gpurun_out/record_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-timeout -k 10 400 python3 bench.py $extra > $out/bench.log 2> $out/bench.err
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py $extra > $out/stats.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -o run -- python3 bench.py $extra --steps 4 --warmup 1 --no-cpu-baseline --no-trace-phase > $out/pmc_fetch.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -o run -- python3 bench.py $extra --steps 4 --warmup 1 --no-cpu-baseline --no-trace-phase > $out/pmc_write.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_valu -o run -- python3 bench.py $extra --steps 4 --warmup 1 --no-cpu-baseline --no-trace-phase > $out/pmc_valu.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_l2 -o run -- python3 bench.py $extra --steps 4 --warmup 1 --no-cpu-baseline --no-trace-phase > $out/pmc_l2.log 2>&1
-ls -R $out | head -40
-cat $out/bench.log
+timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.log 2> $out/bench.err
+echo "bench done"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/stats.log 2>&1
+echo "stats done"
+timeout -k 10 300 python3 bench.py --steps 64 --warmup 4 --no-cpu-baseline > $out/bench_64.log 2> $out/bench_64.err
+timeout -k 10 200 python3 bench.py --config C1 --steps 16 --warmup 2 > $out/bench_c1.log 2> $out/bench_c1.err
+timeout -k 10 500 python3 bench.py --config C5 --steps 12 --warmup 3 > $out/bench_c5.log 2> $out/bench_c5.err
+timeout -k 10 300 python3 bench.py --config C5 --no-lights --steps 12 --warmup 3 --no-cpu-baseline > $out/bench_c5_nolights.log 2> $out/bench_c5_nolights.err
+timeout -k 10 600 python3 bench.py --config C4 --steps 6 --warmup 4 > $out/bench_c4.log 2> $out/bench_c4.err
+echo "configs done"
+for s in 2 4 8; do
+  timeout -k 10 200 python3 bench.py --sim-world $s --steps 20 --warmup 5 --no-cpu-baseline > $out/bench_sim$s.log 2> $out/bench_sim$s.err
+done
+ER_BENCH_REHEARSAL=1 timeout -k 10 400 python3 bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline > $out/bench_rehearsal2.log 2> $out/bench_rehearsal2.err
+echo "shares + rehearsal done"
+bash tools/pmc_passes.sh ${tag}_c2 full > $out/pmc_c2.log 2>&1
+bash tools/pmc_passes.sh ${tag}_c4 core --config C4 > $out/pmc_c4.log 2>&1
+bash tools/pmc_passes.sh ${tag}_c5 core --config C5 > $out/pmc_c5.log 2>&1
+echo "pmc done"
+for f in $out/bench*.log; do python3 -c "
+import json
+try:
+    d=json.loads(open('$f').read().strip().splitlines()[-1]); r=d['roofline']
+    print('$f', d['value'], d['unit'], 'ms/step', d['ms_per_step'], 'frac', r['frac'], 'of measured', r['frac_of_measured'], 'n_gpus', d['n_gpus'], 'sched', d['config']['schedule'], (d.get('cpu_baseline') or {}).get('value'))
+except Exception as e: print('$f FAILED', e)
+"; done
