@@ -146,3 +146,42 @@ def test_native_communicator_beside_torch_distributed_rccl():
         assert float(t[0]) == 1.0
     finally:
         dist.destroy_process_group()
+
+
+def test_c3_eight_ranks_of_the_c2_frame_gathered_equal_the_single_gpu_frame():
+    """BASELINE config 3 as far as one GPU can run it: the 1M-triangle C2 scene at 1920x1080, its 8x8 tiles dealt to EIGHT ranks
+    ((tx + ty) % 8, one ErScene per rank, all on this box's one GPU in one process), every rank renders its share -- an eighth of
+    the frame is 1 012 pixels per CU, the 12-wave form of the streaming kernel -- and every plane is gathered to rank 0 through the
+    library's own er_gather_pass over the in-process transport (the RCCL transport refuses two ranks on one device; the wire is the
+    only thing that differs from the 8-GPU run).  The gathered frame must equal the single-GPU frame bit for bit in all five planes;
+    the ranks' paths must add up to the frame, once.  Reference shape: one pass per sample over all pixels (src/kernel.cpp:680-706),
+    read-back of src/Managers.cpp:287-302."""
+    lib = abi.load()
+    sc = scenes.soup(1_000_000, 1920, 1080, seed=12345)
+    spp, mb = 2, 8
+    full = gpu_render(sc, spp, max_bounces=mb)
+    world, root = 8, 0
+    comms = (C.c_void_p * world)()
+    abi.check(lib.er_debug_comm_create_local(world, comms))
+    rms = []
+    for r in range(world):
+        rm = render.RenderingManager(render.RenderParameters(max_bounces=mb, rank=r, world=world))
+        rm.start_rendering(sc)
+        rm.render(spp, blocking=False)
+        rms.append(rm)
+    paths = 0
+    for rm in rms:
+        rm.wait()
+        paths += rm.counters()["paths"]
+        assert rm.profile()["schedule"] == abi.FLAG_STREAM
+    assert paths == 1920 * 1080 * spp
+    for p in range(abi.PASS_COUNT):
+        for r in [x for x in range(world) if x != root] + [root]:
+            abi.check(lib.er_gather_pass(rms[r].handle, p, comms[r], root))
+    for name in abi.PASS_NAMES:
+        got = rms[root].get_pass(name)
+        assert (got.view(np.uint32) == full[name].view(np.uint32)).all(), name
+    for rm in rms:
+        rm.close()
+    for c in comms:
+        lib.er_comm_destroy(c)
