@@ -599,14 +599,14 @@ int er_scene_stream_status(ErScene* s, const char* who) {
 // shader wave for the next call.  Measured with the product kernel at 12 / 11 tracer waves (profiles/r04_adaptive_split.log): C2 0.90 /
 // 0.91 full, 12 + 4 faster by 4.5 %; C4 0.84 / 0.92, 11 + 5 faster by 3 %; C5 with lights 0.75 / 0.88, 11 + 5 faster by 5 %.  Lanes
 // that ARE full say nothing (C2 at 11 + 5 and C4 at 11 + 5 look alike), so the split only ever moves this way: one wave per completed
-// call while the lanes are under 0.86 full, down to 10 + 6 (7 + 5 of 12 waves).  The image does not depend on the split.
+// call while the lanes are under 0.85 full, down to 10 + 6 (7 + 5 of 12 waves).  The image does not depend on the split.
 static void er_stream_adapt(ErScene* s) {
     static const bool verbose = getenv("ER_STREAM_VERBOSE") != nullptr;
     if (verbose && (s->params.flags & ER_FLAG_STREAM) && !s->stream_adapt) fprintf(stderr, "[er_stream] tracer lanes %.3f full at %u + %u waves (fixed split)\n", s->stream_busy, s->stream_tracers, s->stream_waves - s->stream_tracers);
     if (!s->stream_adapt || !(s->params.flags & ER_FLAG_STREAM) || s->stream_busy <= 0.0) return;
     const uint32_t lo = s->stream_waves == 12 ? 7u : 10u;
     const uint32_t before = s->stream_tracers;
-    if (s->stream_busy < 0.86 && s->stream_tracers > lo) s->stream_tracers--;
+    if (s->stream_busy < 0.85 && s->stream_tracers > lo) s->stream_tracers--;
     if (verbose) fprintf(stderr, "[er_stream] tracer lanes %.3f full at %u + %u waves -> %u + %u\n", s->stream_busy, before, s->stream_waves - before, s->stream_tracers, s->stream_waves - s->stream_tracers);
 }
 
