@@ -355,6 +355,9 @@ ERD int trace_cold(const DevScene& S, int* stack, const Ray& ray, int skip_slot,
 // closest-hit result of a finished traversal: the winning slot (or -1) under the reference's exact metric
 template <bool COUNT>
 ERD int resolve_closest(const DevScene& S, int* stack2, const Ray& ray, int hslot, int h2, unsigned& c_nodes, unsigned& c_tris) {
+#ifdef ER_EXPERIMENT_NO_COLD
+    return hslot;      // (diagnostic: what would the step cost without the inlined exact resolves?  WRONG results on ties)
+#endif
     if (h2 == -2) {          // more than two candidates inside one t-interval: exact scalar traversal
         return trace_cold<COUNT, false>(S, stack2, ray, -1, __builtin_inff(), c_nodes, c_tris);
     }
@@ -368,6 +371,9 @@ ERD int resolve_closest(const DevScene& S, int* stack2, const Ray& ray, int hslo
 template <bool COUNT>
 ERD bool resolve_shadow(const DevScene& S, int* stack2, const Ray& sr, int self_slot, float d_self, int occ, int ca, int cb,
                         unsigned& c_nodes, unsigned& c_tris) {
+#ifdef ER_EXPERIMENT_NO_COLD
+    return occ != 0;
+#endif
     if (occ == 3) return trace_cold<COUNT, true>(S, stack2, sr, self_slot, d_self, c_nodes, c_tris) >= 0;
     if (occ == 2) {
         bool nearer = exact_distance(S, (uint32_t)ca, sr) < d_self;
