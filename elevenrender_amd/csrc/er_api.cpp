@@ -601,7 +601,7 @@ int er_scene_stream_status(ErScene* s, const char* who) {
 // that ARE full say nothing (C2 at 11 + 5 and C4 at 11 + 5 look alike), so the split only ever moves this way: one wave per completed
 // call while the lanes are under 0.85 full, down to 10 + 6 (7 + 5 of 12 waves).  The image does not depend on the split.
 static void er_stream_adapt(ErScene* s) {
-    static const bool verbose = getenv("ER_STREAM_VERBOSE") != nullptr;
+    const bool verbose = getenv("ER_STREAM_VERBOSE") != nullptr;      // (read per call: a test turns it on for one render)
     if (verbose && (s->params.flags & ER_FLAG_STREAM) && !s->stream_adapt) fprintf(stderr, "[er_stream] tracer lanes %.3f full at %u + %u waves (fixed split)\n", s->stream_busy, s->stream_tracers, s->stream_waves - s->stream_tracers);
     if (!s->stream_adapt || !(s->params.flags & ER_FLAG_STREAM) || s->stream_busy <= 0.0) return;
     const uint32_t lo = s->stream_waves == 12 ? 7u : 10u;

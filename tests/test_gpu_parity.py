@@ -460,3 +460,30 @@ def test_two_threads_reading_two_passes_of_one_scene_each_get_their_own():
         t.join()
     rm.close()
     assert not wrong, wrong
+
+
+def test_adaptive_tracer_shader_split_does_not_change_the_image(monkeypatch, capfd):
+    """After every completed call the library may turn one tracer wave of the streaming kernel into a shader wave (er_stream_adapt in
+    csrc/er_api.cpp: by the lane occupancy the kernel counts).  Whatever it decides, the planes are those of a fixed split: a frame of
+    1.06 M pixels (4 160 per CU: the adaptation is on) in three calls with the adaptation on == the same calls at a fixed 12 + 4 and at a
+    fixed 10 + 6; the verbose line shows that the occupancy was read after each call and that the split only ever moves towards more
+    shader waves."""
+    sc = scenes.soup(60_000, 1280, 832, seed=31, hdri_size=(256, 128))
+    monkeypatch.setenv("ER_STREAM_TRACERS", "12")
+    fixed12 = gpu_render(sc, 6, max_bounces=8, flags=abi.FLAG_STREAM, chunks=[2, 2, 2])
+    monkeypatch.setenv("ER_STREAM_TRACERS", "10")
+    fixed10 = gpu_render(sc, 6, max_bounces=8, flags=abi.FLAG_STREAM, chunks=[2, 2, 2])
+    monkeypatch.delenv("ER_STREAM_TRACERS")
+    monkeypatch.setenv("ER_STREAM_ADAPT", "1")
+    monkeypatch.setenv("ER_STREAM_VERBOSE", "1")
+    capfd.readouterr()
+    adaptive = gpu_render(sc, 6, max_bounces=8, flags=abi.FLAG_STREAM, chunks=[2, 2, 2])
+    err = capfd.readouterr().err
+    for other in (fixed10, adaptive):
+        for p in ("beauty", "normal", "tangent", "bitangent"):
+            assert (fixed12[p].view(np.uint32) == other[p].view(np.uint32)).all(), p
+        assert (fixed12["rng"] == other["rng"]).all() and (fixed12["samples"] == other["samples"]).all()
+    lines = [l for l in err.splitlines() if l.startswith("[er_stream] tracer lanes")]
+    assert len(lines) >= 3, err
+    tracers = [int(l.split("->")[1].split("+")[0]) for l in lines if "->" in l]
+    assert tracers and all(a >= b for a, b in zip(tracers, tracers[1:])) and min(tracers) >= 10 and max(tracers) <= 12, lines
