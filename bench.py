@@ -516,7 +516,10 @@ def main():
                          "warmup_launch_ms": round(region["warmup_ms"], 3) if region.get("warmup_ms") is not None else None,
                          "trace_ms_total": round(prof["trace_ms"], 3), "shade_ms_total": round(prof["shade_ms"], 3),
                          "region_ms": round(kernel_ms, 3),
-                         "whole_path_GBps": round(path_b / wall_s / 1e9, 2),
+                         # SURVEY 8(d)'s FULL per-pixel-sample formula (64 V + 36 T + 112 H + 12 X + 4 ceil(log2 P) S + 112) over the same region: the
+                         # streaming kernel runs the whole path, so this is its algorithmic rate by the survey's definition; `achieved` / `frac` keep
+                         # to the traversal terms alone (north_star: "during BVH traversal"), as in every earlier round
+                         "whole_path_GBps": round(path_b / wall_s / 1e9, 2), "frac_whole_path": round(path_b / wall_s / 1e9 / HBM_PEAK_GBS, 4),
                          "node_visits_per_ray": round(ci["node_visits"] / max(1, ci["rays"]), 2),
                          "tri_tests_per_ray": round(ci["tri_tests"] / max(1, ci["rays"]), 2),
                          # lane occupancy of er_wf_trace's loop in the instrumented replay: share of the 64 lanes that held a
