@@ -3,7 +3,7 @@
 #   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU, fused schedule
 #   bash tools/sweep_r04.sh c4     -> C4: tracer/shader split, ring-visit and batch thresholds
 set -o pipefail
-what=${1:?sim8|c4|c4w|shares|knobs}
+what=${1:?sim8|c4|c4w|shares|knobs|retune}
 out=gpurun_out/sweep_r04_$what
 mkdir -p $out
 line() { python3 -c "
@@ -61,4 +61,13 @@ if [ "$what" = knobs ]; then      # C2 after the split wait: batch / refill thre
   run prio2 ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_p2.so -- $S
   run prio3 ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_p3.so -- $S
   run base2 X=1 -- $S
+fi
+if [ "$what" = retune ]; then      # after -fno-slp-vectorize: the tracer / shader split per config again (fixed splits), thresholds
+  for t in 11 12 13; do run c2_t$t ER_STREAM_TRACERS=$t -- --steps 20 --warmup 5; done
+  for t in 10 11 12; do run c5_t$t ER_STREAM_TRACERS=$t -- --config C5 --steps 12 --warmup 3; done
+  for t in 11 12 13; do run c4_t$t ER_STREAM_TRACERS=$t -- --config C4 --steps 6 --warmup 2; done
+  run c2_refill8 ER_STREAM_REFILL_MIN=8 -- --steps 20 --warmup 5
+  run c2_refill16 ER_STREAM_REFILL_MIN=16 -- --steps 20 --warmup 5
+  run c2_batch48 ER_STREAM_BATCH_MIN=48 -- --steps 20 --warmup 5
+  for s in 8; do run sim8_w12 ER_STREAM_WAVES=12 -- --sim-world 8 --steps 20 --warmup 5; run sim8_w16 ER_STREAM_WAVES=16 -- --sim-world 8 --steps 20 --warmup 5; done
 fi
