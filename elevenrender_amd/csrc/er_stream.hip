@@ -110,9 +110,11 @@ static_assert((1u << ST_RQ_LOG2) >= ER_STREAM_SLOTS && (1u << ST_RQ_LOG2) >= 4u 
 // north_star: "top BVH levels staged in LDS".  Every workgroup keeps the first wide nodes in LDS (the tree is stored
 // breadth-first: 585 = levels 0-3, 47 KB) and the tracer lanes whose node is one of them read it with ds_read_b128 instead of
 // five global loads: 9 of a ray's 21 node visits on C2.  Measured on C2 with the first tracer: 0 nodes 1240, 73 -> 1274,
-// 256 -> 1286, 585 -> 1330, 800 -> 1331 Msamples/s (profiles/r02_ab_top_levels_in_lds.log).
+// 256 -> 1286, 585 -> 1330, 800 -> 1331 Msamples/s (profiles/r02_ab_top_levels_in_lds.log).  Round 4: the 16 KB of LDS the
+// backend no longer takes for itself (-fno-slp-vectorize) hold 315 nodes of level 4 as well: C2 +0.2 %, C4 +1.5 %
+// (profiles/r04_ab_top_nodes_900.log); a deeper LDS stack instead (10 entries): -0.5 %.
 #ifndef ER_STREAM_TOP_NODES
-#define ER_STREAM_TOP_NODES 585
+#define ER_STREAM_TOP_NODES 900
 #endif
 #define ST_MAX_TRACERS 13
 enum { C_LIVE = 0, C_DONE, C_INIT, C_WORDS };

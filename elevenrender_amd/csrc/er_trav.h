@@ -19,7 +19,9 @@
 #pragma once
 #include "er_device.h"
 
-#define WF_LDS_STACK 8
+#ifndef WF_LDS_STACK
+#define WF_LDS_STACK 8      // per-lane stack entries in LDS (deeper levels go to the HBM spill area); 10 and 12 measured on C4 and C2: no difference
+#endif
 
 namespace erd {
 
