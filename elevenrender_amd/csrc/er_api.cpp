@@ -302,7 +302,8 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
                 std::vector<uint32_t> deal;
                 const uint32_t most = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), (s->x_res + ER_TILE - 1) / ER_TILE, (uint32_t)cus,
                                                            stream_xcd_aware(owned.size(), (uint32_t)cus), deal);
-                sched = (size_t)most * 64u > ER_STREAM_MAX_RING ? ER_FLAG_WAVEFRONT : ER_FLAG_STREAM;
+                // (and the streaming schedule carries a pixel as px | py << 16)
+                sched = ((size_t)most * 64u > ER_STREAM_MAX_RING || s->x_res > 65535u || s->y_res > 65535u) ? ER_FLAG_WAVEFRONT : ER_FLAG_STREAM;
             }
         }
         else if (forced & (forced - 1)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: more than one schedule flag");
@@ -325,9 +326,12 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         // 12 tracer + 4 shader waves (shader waves at issue priority 1; finished and escaped paths handled in batches of their own,
         // er_stream.hip); before: 11 + 5, round 2: 10 + 6.  With the point-light extension a shading step is a third longer (a second
         // BRDF evaluation, a second shadow query): 11 + 5 there (C5: 1 188 vs 1 130 Msamples/s, profiles/r03_ab_split_by_config.log)
-        // ... to begin with; after every completed call the split follows how full the tracer lanes were (er_stream_adapt: C4 settles at
-        // 11 + 5 after its first long call, C2 stays at 12 + 4)
-        s->stream_tracers = lights_on ? 11 : 12;
+        // 13 tracer + 3 shader waves where the shading step is at its cheapest -- plain materials, a scene that lives in the caches
+        // (C2: 1 787 vs 1 715 Msamples/s at 12 + 4) -- and 12 + 4 where it costs more: textured materials (C5 without lights: 1 560 vs
+        // 1 489 at 13 + 3), point lights (C5: 1 350 vs 1 234), or a scene beyond the Infinity Cache (C4, 10 M triangles: 1 562 vs 1 483)
+        // (profiles/r04_sweep_split_after_shader_diet.log).  That is the split to begin with; after every completed call it follows how
+        // full the tracer lanes were (er_stream_adapt: a scene of another kind that starves 13 tracers gets 12 after its first call).
+        s->stream_tracers = (lights_on || !s->textures.empty() || s->tri_count > 4000000u) ? 12 : 13;
         // A workgroup that owns hardly more pixels than it has slots (an eighth of a 1080p frame: 1 012 pixels per CU) cannot fill 12 tracer
         // waves -- a pixel's samples are one RNG stream, so pixels in flight are all the parallelism there is -- and runs faster as 9 tracer +
         // 3 shader waves of 168 registers (the shading step then spills 34 registers instead of 111 and three shader waves serve what four
@@ -335,13 +339,13 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         s->stream_waves = 16;
         {
             const size_t px_per_cu = owned.size() * 64 / std::max<uint32_t>(1u, s->stream_blocks);
-            if (px_per_cu <= ER_STREAM_SMALL_SHARE) { s->stream_waves = 12; s->stream_tracers = lights_on ? 8 : 9; }
+            if (px_per_cu <= ER_STREAM_SMALL_SHARE) { s->stream_waves = 12; s->stream_tracers = 9; }
             // the lane occupancy says something about the balance of the two roles only where pixels are plentiful: a share of a few
             // pixels per slot cannot fill the lanes whatever the split (an eighth of a 1080p frame: 0.59 at the fastest split)
             // (nor in the instrumented kernel of ER_FLAG_COUNTERS, whose slower tracer loop shifts the balance)
             s->stream_adapt = px_per_cu >= 4u * ER_STREAM_SLOTS && !(p->flags & ER_FLAG_COUNTERS);
         }
-        if (const char* e = getenv("ER_STREAM_WAVES")) { s->stream_waves = atoi(e) == 12 ? 12 : 16; s->stream_tracers = s->stream_waves == 12 ? (lights_on ? 8 : 9) : (lights_on ? 11 : 12); }   // A/B knob
+        if (const char* e = getenv("ER_STREAM_WAVES")) { s->stream_waves = atoi(e) == 12 ? 12 : 16; s->stream_tracers = s->stream_waves == 12 ? 9u : ((lights_on || !s->textures.empty() || s->tri_count > 4000000u) ? 12u : 13u); }   // A/B knob
         if (const char* e = getenv("ER_STREAM_TRACERS")) { s->stream_tracers = (uint32_t)std::min(13, std::max(1, atoi(e))); s->stream_adapt = false; }   // tuning knob: fixed split
         if (const char* e = getenv("ER_STREAM_ADAPT")) s->stream_adapt = atoi(e) != 0;
         const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
@@ -360,6 +364,8 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         const uint32_t most = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), (s->x_res + ER_TILE - 1) / ER_TILE, s->stream_blocks, xcd_aware, deal);
         if ((rc = upload(s->d_deal, deal.data(), deal.size(), s->stream)) != ER_OK) return rc;
         HIP_TRY(hipStreamSynchronize(s->stream));          // (`deal` goes out of scope)
+        if (s->x_res > 65535u || s->y_res > 65535u)
+            return fail(ER_ERR_INVALID_ARG, "er_render_begin: ER_FLAG_STREAM carries a pixel as x | y << 16: frames up to 65535 x 65535; use ER_FLAG_WAVEFRONT (the automatic choice does)");
         s->stream_ring_cap = 64u;
         while (s->stream_ring_cap < most * 64u) s->stream_ring_cap <<= 1;
         if (s->stream_ring_cap > ER_STREAM_MAX_RING)
@@ -462,6 +468,13 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     D.tiles_x = (s->x_res + ER_TILE - 1) / ER_TILE;
     D.tiles_y = (s->y_res + ER_TILE - 1) / ER_TILE;
     D.max_bounces = s->params.max_bounces;
+    {   // power-of-two sides everywhere: texture coordinates wrap with a mask instead of a signed division (er_device.h wrap_abs)
+        auto pow2 = [](int32_t v) { return v > 0 && (v & (v - 1)) == 0; };
+        bool all = pow2(hd.width) && pow2(hd.height);
+        for (const HostTex& t : s->textures) all = all && pow2(t.width) && pow2(t.height);
+        D.tex_pow2 = all ? 1u : 0u;
+        if (const char* e = getenv("ER_TEX_POW2")) D.tex_pow2 = (atoi(e) != 0 && all) ? 1u : 0u;      // A/B knob: 0 = always the division
+    }
     D.ext_flags = s->params.flags & (ER_FLAG_POINT_LIGHTS | ER_FLAG_MIS);
     D.lights = s->d_lights.p;
     D.light_count = (uint32_t)s->point_lights.size();
@@ -471,6 +484,12 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     D.owned_tiles = s->d_owned.p;
     D.owned_tile_count = (uint32_t)owned.size();
     D.counters = s->d_counters.p;
+    {   // the camera's rotation sines / cosines, once, with the functions the device would call (er_math.h: one implementation for both sides)
+        const erd::CamTrig t = erd::camera_trig(D.cam);
+        D.cam_cx = t.cx; D.cam_sx = t.sx; D.cam_cy = t.cy; D.cam_sy = t.sy; D.cam_cz = t.cz; D.cam_sz = t.sz;
+        D.cam_trig_valid = getenv("ER_CAM_TRIG_ON_DEVICE") ? 0u : 1u;      // (A/B and test knob: 1 = use the host's values)
+    }
+    if ((rc = upload(s->d_dev, &D, 1, s->stream)) != ER_OK) return rc;
 
     er_launch_setup(D, s->stream);
     HIP_TRY(hipGetLastError());
@@ -517,7 +536,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
         er_launch_fused(s->dev, s->d_ticket.p, s->d_spill.p, n, count, s->fused_blocks, s->stream);
     } else if (s->params.flags & ER_FLAG_STREAM) {
         HIP_TRY(hipMemsetAsync(s->stream_ctl + 2, 0, 4 * sizeof(uint32_t), s->stream));      // the call's lane-occupancy counts
-        er_launch_stream(s->dev, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_deal.p, (uint32_t)s->d_deal.n, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
+        er_launch_stream(s->dev, s->d_dev.p, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_deal.p, (uint32_t)s->d_deal.n, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
                          s->stream_blocks, s->stream_tracers, s->stream_waves, s->stream);
     } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
         er_launch_render(s->dev, n, count, s->stream);
@@ -596,10 +615,10 @@ int er_scene_stream_status(ErScene* s, const char* who) {
 // The two roles of the streaming kernel feed each other, and which one is short depends on the scene: how long a ray's traversal is
 // against how long its shading step is.  What the tracers' lanes say after a call (counted by the kernel itself, two scalar
 // operations per iteration): clearly not full = the shader waves cannot produce rays fast enough, and one tracer wave becomes a
-// shader wave for the next call.  Measured with the product kernel at 12 / 11 tracer waves (profiles/r04_adaptive_split.log): C2 0.90 /
-// 0.91 full, 12 + 4 faster by 4.5 %; C4 0.84 / 0.92, 11 + 5 faster by 3 %; C5 with lights 0.75 / 0.88, 11 + 5 faster by 5 %.  Lanes
-// that ARE full say nothing (C2 at 11 + 5 and C4 at 11 + 5 look alike), so the split only ever moves this way: one wave per completed
-// call while the lanes are under 0.85 full, down to 10 + 6 (7 + 5 of 12 waves).  The image does not depend on the split.
+// shader wave for the next call.  Measured with the product kernel (profiles/r04_sweep_split_after_shader_diet.log): C2 0.89-0.90 full
+// at 13 + 3 (its best split); C4 0.81-0.85 at 13 + 3 and 0.92 at 12 + 4 (its best); C5 with lights 0.75 at 13 + 3, 0.90 at 12 + 4 (its
+// best).  Lanes that ARE full say nothing (C4 looks alike at 12 + 4 and 11 + 5), so the split only ever moves this way: one wave per
+// completed call while the lanes are under 0.85 full, down to 10 + 6 (7 + 5 of 12 waves).  The image does not depend on the split.
 static void er_stream_adapt(ErScene* s) {
     const bool verbose = getenv("ER_STREAM_VERBOSE") != nullptr;      // (read per call: a test turns it on for one render)
     if (verbose && (s->params.flags & ER_FLAG_STREAM) && !s->stream_adapt) fprintf(stderr, "[er_stream] tracer lanes %.3f full at %u + %u waves (fixed split)\n", s->stream_busy, s->stream_tracers, s->stream_waves - s->stream_tracers);

@@ -62,6 +62,12 @@ struct DevScene {
     ErCamera cam;
     uint32_t x_res, y_res, tiles_x, tiles_y;
     uint32_t max_bounces;
+    uint32_t tex_pow2;          // 1 when every texture and the HDRI have power-of-two sides (tex_coords then wraps with a mask)
+    // the camera's six rotation sines / cosines (src/kernel.cpp:371-473 recomputes them for every sample): evaluated ONCE on the host
+    // with the same ermath functions -- er_math.h is one implementation for both sides, binary64 without FMA: the same bits -- by
+    // camera_trig() below; cam_trig_valid = 0 makes camera_ray compute them itself (the other schedules' kernels leave it 0 or 1 alike)
+    float cam_cx, cam_sx, cam_cy, cam_sy, cam_cz, cam_sz;
+    uint32_t cam_trig_valid;
     // build-defined extensions (er_shade.h): ER_FLAG_POINT_LIGHTS / ER_FLAG_MIS bits of the render flags
     uint32_t ext_flags;
     const ErPointLight* lights;
@@ -153,8 +159,18 @@ ERD float rng_next(uint32_t& state) {
 }
 
 // ---- camera, src/kernel.cpp:371-473 ----------------------------------------------
+struct CamTrig { float cx, sx, cy, sy, cz, sz; };
+// the rotation's sines and cosines exactly as camera_ray evaluates them (host and device: the same expressions on the same ermath)
+__host__ __device__ inline CamTrig camera_trig(const ErCamera& cam) {
+    using namespace ermath;
+    const float k = 3.14159265358979323846f / 180.0f;      // PIF / 180.0f
+    const float rx = cam.rotation.x * k, ry = cam.rotation.y * k, rz = cam.rotation.z * k;
+    CamTrig t;
+    t.cx = er_cos(rx); t.sx = er_sin(rx); t.cy = er_cos(ry); t.sy = er_sin(ry); t.cz = er_cos(rz); t.sz = er_sin(rz);
+    return t;
+}
 ERD Ray camera_ray(const ErCamera& cam, int x, int y, uint32_t x_res, uint32_t y_res,
-                   float r1, float r2, float r3, float r4, float r5) {
+                   float r1, float r2, float r3, float r4, float r5, const CamTrig* pre = nullptr) {
     using namespace ermath;
     F3 cpos = f3(cam.position.x, cam.position.y, cam.position.z);
     float dx = cpos.x + ((float)x) / ((float)x_res) * cam.sensor_width;
@@ -164,8 +180,8 @@ ERD Ray camera_ray(const ErCamera& cam, int x, int y, uint32_t x_res, uint32_t y
     float rx = (1.0f / (float)x_res) * (r1 - 0.5f) * cam.sensor_width;
     float ry = (1.0f / (float)y_res) * (r2 - 0.5f) * cam.sensor_height;
     float SPx = odx + rx, SPy = ody + ry, SPz = cpos.z + cam.focal_length;
-    F3 rot = f3(cam.rotation.x, cam.rotation.y, cam.rotation.z) * (PIF / 180.0f);
-    float cx = er_cos(rot.x), sx = er_sin(rot.x), cy = er_cos(rot.y), sy = er_sin(rot.y), cz = er_cos(rot.z), sz = er_sin(rot.z);
+    const CamTrig tr = pre ? *pre : camera_trig(cam);      // (rot = rotation * (PI / 180), then the six er_cos / er_sin: camera_trig)
+    const float cx = tr.cx, sx = tr.sx, cy = tr.cy, sy = tr.sy, cz = tr.cz, sz = tr.sz;
     F3 dir = f3(SPx, SPy, SPz) - cpos;
     F3 dX = f3(dir.x, dir.y * cx - dir.z * sx, dir.y * sx + dir.z * cx);
     F3 dY = f3(dX.x * cy + dX.z * sy, dX.y, dX.z * cy - dX.x * sy);
@@ -363,11 +379,18 @@ ERD int trace(const DevScene& S, int* stack /* LDS, stride 64 ints */, const Ray
 }
 
 // ---- textures, src/Texture.cpp:172-236 -------------------------------------------
+// |x % w| of C's truncating `%` (what `x %= w; if (x < 0) x *= -1;` of src/Texture.cpp:176-180 leaves) equals |x| % w, and for a
+// power-of-two w that is |x| & (w - 1): two operations instead of the ~35 of a signed division by a run-time value -- six of them ran
+// per shading step (HDRI texel, its pdf, the CDF index), profiles/r04_shader_function_budget.txt.  Same integers for every input:
+// |INT_MIN| wraps to INT_MIN in both forms (its low bits are zero, so the mask gives 0 = |INT_MIN % w|).
+ERD int wrap_abs(int x, int w, bool pow2) {      // pow2: EVERY texture of the scene has power-of-two sides (DevScene::tex_pow2, wave-uniform)
+    if (pow2) return (int)((x < 0 ? 0u - (unsigned)x : (unsigned)x) & (unsigned)(w - 1));
+    x %= w;
+    return x < 0 ? -x : x;
+}
 ERD F3 tex_coords(const DevScene& S, const DevTex& t, int x, int y) {
-    x %= t.width;
-    y %= t.height;
-    if (x < 0) x *= -1;
-    if (y < 0) y *= -1;
+    x = wrap_abs(x, t.width, S.tex_pow2 != 0u);
+    y = wrap_abs(y, t.height, S.tex_pow2 != 0u);
     const float* d = S.tex_pool + t.offset;
     F3 pixel = f3s(0);
     if (t.channels == 1) {

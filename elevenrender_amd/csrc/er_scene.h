@@ -176,6 +176,7 @@ struct ErScene {
     DevBuf<float> d_tex_pool, d_cdf;
     DevBuf<uint32_t> d_samples, d_rng, d_owned;
     DevBuf<DevCounters> d_counters;
+    DevBuf<DevScene> d_dev;      // device copy of `dev`: the streaming kernel reads the scene descriptor through a pointer
     DevBuf<float4> d_wf4;        // 11 float4 arrays of the wavefront state, back to back
     DevBuf<uint32_t> d_wf1;      // hit, left, occluded, 4 queues, counts
     DevBuf<uint2> d_spill;

@@ -28,7 +28,8 @@ struct WfState;
 // <= ER_STREAM_MAX_RING); status: five words at an address that is 4 (mod 8): [0] 0 unless a wave's watchdog or a ring guard fired,
 // [1..2] iterations of all tracer waves' loops and [3..4] the lanes that held a ray in them, both added up as 64-bit counts by the
 // launch (the caller zeroes them before it).
-void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
+// S_dev: a device copy of S (the kernel reads the scene descriptor from constant memory, not from its arguments).
+void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
                       uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, hipStream_t stream);
 // the deal of the owned tiles to the workgroups (device copy of `out` = `deal` above, deal_count = out.size()); returns the most tiles of one workgroup
 uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, bool xcd_aware, std::vector<uint32_t>& out);

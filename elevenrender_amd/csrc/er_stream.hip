@@ -241,13 +241,19 @@ __device__ __forceinline__ bool st_pixel_of(const DevScene& S, const uint32_t* d
     return px < S.x_res && py < S.y_res;
 }
 
-// first camera ray of a sample of pixel idx in slot g (src/kernel.cpp:492-506); the pixel's RNG state comes from its plane
-__device__ __forceinline__ void st_begin_sample(const DevScene& S, const StState& W, uint32_t g, uint32_t idx, uint32_t left) {
-    const uint32_t px = idx % S.x_res, py = idx / S.x_res;
-    uint32_t rs = S.rng[idx];
+// A pixel travels through the slots and the pixel ring as px | py << 16 (both < 65 536: er_api.cpp checks), so that nobody divides by
+// the run-time width to get its coordinates back; its index in the planes is py * x_res + px.
+#define ST_PXY(px, py) ((uint32_t)(px) | ((uint32_t)(py) << 16))
+__device__ __forceinline__ uint32_t st_pixel_index(const DevScene& S, uint32_t pxy) { return (pxy >> 16) * S.x_res + (pxy & 0xFFFFu); }
+
+// first camera ray of a sample of pixel pxy in slot g (src/kernel.cpp:492-506); the pixel's RNG state comes from its plane
+__device__ __forceinline__ void st_begin_sample(const DevScene& S, const StState& W, uint32_t g, uint32_t pxy, uint32_t left) {
+    const uint32_t px = pxy & 0xFFFFu, py = pxy >> 16;
+    uint32_t rs = S.rng[py * S.x_res + px];
     float c1 = rng_next(rs), c2 = rng_next(rs), c3 = rng_next(rs), c4 = rng_next(rs), c5 = rng_next(rs);
-    const Ray ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5);
-    W.pix(g) = idx;
+    const CamTrig trig = {S.cam_cx, S.cam_sx, S.cam_cy, S.cam_sy, S.cam_cz, S.cam_sz};      // (evaluated once on the host: er_api.cpp)
+    const Ray ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5, S.cam_trig_valid ? &trig : nullptr);
+    W.pix(g) = pxy;
     W.ray_o(g) = make_float4(ray.o.x, ray.o.y, ray.o.z, 0.0f);
     W.ray_d(g) = make_float4(ray.d.x, ray.d.y, ray.d.z, -1.0f);
     W.light(g) = make_float4(0.0f, 0.0f, 0.0f, __builtin_bit_cast(float, rs));
@@ -273,8 +279,11 @@ __device__ __forceinline__ void st_write_result(const StState& W, uint32_t rec, 
 }  // namespace
 
 template <bool COUNT, bool EXT, uint32_t ST_THREADS>
-__global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StState W, const uint32_t* deal, uint32_t deal_count, uint2* ring_base, uint32_t ring_cap,
+__global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __attribute__((address_space(4)))* Sp, StState W, const uint32_t* deal, uint32_t deal_count, uint2* ring_base, uint32_t ring_cap,
                                                           uint32_t* status, uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min, uint32_t fin_min) {
+    // The scene descriptor lives in constant memory and is read with scalar loads where it is used.  As a by-value kernel argument its
+    // ~60 dwords stayed in SGPRs for the whole kernel and the shading step moved 585 scalar spills to and from VGPR lanes (round 4).
+    const DevScene& S = *(const DevScene*)Sp;
     constexpr uint32_t RQ_LOG2 = ST_RQ_LOG2, SLOTS = ER_STREAM_SLOTS, TOP_NODES = ER_STREAM_TOP_NODES;
     __shared__ uint32_t s_rq[1u << RQ_LOG2];
     __shared__ uint32_t s_sq[1u << ST_SQ_LOG2];
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
         const bool valid = n_samples > 0 && k < ring_cap && st_pixel_of(S, deal, deal_count, blockIdx.x, gridDim.x, k, px, py);
         const uint32_t v = st_reserve(&s_ctl[C_INIT], valid);      // (rank among the valid pixels; order does not matter)
         const bool to_slot = valid && v < SLOTS;
-        const uint32_t idx = py * S.x_res + px;
+        const uint32_t idx = ST_PXY(px, py);
         if (to_slot) {
             st_begin_sample(S, W, g0 + v, idx, n_samples);
             s_wait[v] = 1u;
@@ -671,7 +680,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 }
             } else if (have) {
                 ER_TPS(6);
-                const uint32_t idx = W.pix(slot);
+                const uint32_t pxy = W.pix(slot);
+                const uint32_t idx = st_pixel_index(S, pxy);
                 const float4 L4 = W.light(slot);
                 F3 light = f3(L4.x, L4.y, L4.z);
                 rs = __builtin_bit_cast(uint32_t, L4.w);
@@ -718,7 +728,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(DevScene S, StSta
                 c_paths++;
                 // the sample is done: the pixel goes back to the ring (below, as a wave) and the slot takes the next one
                 left_after = W.left(slot) - 1;
-                done_idx = idx;
+                done_idx = pxy;
                 want_pixel = true;
             }
             ER_MARK("shader_pixel_ring");
@@ -884,7 +894,7 @@ uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t ti
     return maxk;
 }
 
-void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
+void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
                       uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, hipStream_t stream) {
     static const uint32_t refill_min = [] {
         const char* e = getenv("ER_STREAM_REFILL_MIN");
@@ -914,8 +924,9 @@ void er_launch_stream(const DevScene& S, void* records, uint32_t slots, bool lig
     st.spill = (uint2*)spill;
     st.slots = slots;
     st.stride = er_stream_record_bytes(lights);
-    if (waves == 12u) hipLaunchKernelGGL(k12, dim3(blocks), dim3(768), 0, stream, S, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
-    else hipLaunchKernelGGL(k16, dim3(blocks), dim3(1024), 0, stream, S, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
+    const DevScene __attribute__((address_space(4)))* dS = (const DevScene __attribute__((address_space(4)))*)S_dev;
+    if (waves == 12u) hipLaunchKernelGGL(k12, dim3(blocks), dim3(768), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
+    else hipLaunchKernelGGL(k16, dim3(blocks), dim3(1024), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
 }
 
 uint32_t er_stream_record_bytes(bool lights) { return lights ? ST_STRIDE_LIGHTS : ST_STRIDE_PLAIN; }

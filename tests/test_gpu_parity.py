@@ -486,4 +486,4 @@ def test_adaptive_tracer_shader_split_does_not_change_the_image(monkeypatch, cap
     lines = [l for l in err.splitlines() if l.startswith("[er_stream] tracer lanes")]
     assert len(lines) >= 3, err
     tracers = [int(l.split("->")[1].split("+")[0]) for l in lines if "->" in l]
-    assert tracers and all(a >= b for a, b in zip(tracers, tracers[1:])) and min(tracers) >= 10 and max(tracers) <= 12, lines
+    assert tracers and all(a >= b for a, b in zip(tracers, tracers[1:])) and min(tracers) >= 10 and max(tracers) <= 13, lines
