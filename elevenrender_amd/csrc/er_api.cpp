@@ -250,6 +250,15 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         build_ms = bvh.build_ms;
     }
     if ((rc = upload(s->d_materials, s->materials.data(), s->materials.size(), s->stream)) != ER_OK) return rc;
+    std::vector<float4> mat_pre(s->materials.size());
+    for (size_t i = 0; i < s->materials.size(); i++) {      // DevScene::mat_pre: the per-material constants of generate_hit_data and GTR1
+        const ErMaterial& m = s->materials[i];
+        const float a = 0.1f + m.clearcoat_gloss * (0.001f - 0.1f);      // lerpf(0.1f, 0.001f, clearcoatGloss), src/Math.hpp:38-41
+        const float a2 = a * a;
+        mat_pre[i] = make_float4(ermath::er_pow(m.roughness, 2.2f), ermath::er_pow(m.metallic, 2.2f), a < 1.0f ? ermath::er_log(a2) : 0.0f, a < 1.0f ? 1.0f : 0.0f);
+    }
+    if (getenv("ER_MAT_PRE_ON_DEVICE")) for (auto& v : mat_pre) v.w = 0.0f;      // (A/B and test knob: GTR1's logarithm on the device)
+    if ((rc = upload(s->d_mat_pre, mat_pre.data(), mat_pre.size(), s->stream)) != ER_OK) return rc;
     if ((rc = upload(s->d_lights, s->point_lights.data(), s->point_lights.size(), s->stream)) != ER_OK) return rc;
     // point-light queries double the shadow records and the shadow queues of the wavefront schedule (er_wavefront.h)
     const bool lights_on = (p->flags & ER_FLAG_POINT_LIGHTS) != 0 && !s->point_lights.empty();
@@ -455,6 +464,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     D.max_lift = lift_bound;
     D.scene_scale = scene_scale;
     D.materials = s->d_materials.p;
+    D.mat_pre = s->d_mat_pre.p;
     D.textures = s->d_textures.p;
     D.tex_pool = s->d_tex_pool.p;
     D.hdri_tex = hd;

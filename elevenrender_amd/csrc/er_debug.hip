@@ -157,6 +157,7 @@ ERD HitData hd_from(const float* h) {     // the oracle's hd[20] layout
     d.sheen = h[10]; d.opacity = 1.0f;
     d.albedo = f3(h[11], h[12], h[13]); d.tangent = f3(h[14], h[15], h[16]); d.bitangent = f3(h[17], h[18], h[19]);
     d.emission = f3s(0); d.position = f3s(0); d.normal = f3s(0);
+    d.gtr1_log = __builtin_nanf("");      // (no material behind a hand-made HitData: GTR1 evaluates its logarithm itself)
     return d;
 }
 }  // namespace

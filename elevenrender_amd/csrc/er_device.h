@@ -52,6 +52,11 @@ struct DevScene {
     float max_lift, scene_scale; // inputs of the interval bookkeeping in er_wf_trace
     // shading
     const ErMaterial* materials;
+    // per material, evaluated once on the host with the same ermath functions (one implementation for both sides: the same bits):
+    // x = er_pow(roughness, 2.2f), y = er_pow(metallic, 2.2f) -- used when that channel has no texture (src/kernel.cpp:152-153 computes
+    // them at every hit) --, z = er_log(a * a) for a = lerp(0.1, 0.001, clearcoatGloss), the logarithm GTR1 takes at every BRDF
+    // evaluation (src/Disney.cpp:40-46); w = 1 if z is valid (a < 1)
+    const float4* mat_pre;
     const DevTex* textures;
     const float* tex_pool;
     DevTex hdri_tex;
@@ -472,6 +477,7 @@ ERD float hdri_pdf(const DevScene& S, int x, int y) {
 struct HitData {
     float metallic, roughness, clearcoatGloss, clearcoat, anisotropic, transmission, specular,
         specularTint, sheenTint, subsurface, sheen, opacity;
+    float gtr1_log;      // er_log(a * a) of the clearcoat lobe's alpha (a per-material constant: DevScene::mat_pre), NaN = compute it
     F3 emission, albedo;
     F3 position, normal, tangent, bitangent;
 };
@@ -481,11 +487,12 @@ ERD float SchlickFresnel(float u) {
     float m2 = m * m;
     return m2 * m2 * m;
 }
-ERD float GTR1(float NDotH, float a) {
+ERD float GTR1(float NDotH, float a, float log_a2) {      // log_a2 = er_log(a * a), or NaN: evaluated here
     if (a >= 1.0f) return (1.0f / PIF);
     float a2 = a * a;
     float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
-    return (a2 - 1.0f) / (PIF * ermath::er_log(a2) * t);
+    const float lg = log_a2 == log_a2 ? log_a2 : ermath::er_log(a2);
+    return (a2 - 1.0f) / (PIF * lg * t);
 }
 ERD float GTR2_aniso(float NDotH, float HDotX, float HDotY, float ax, float ay) {
     float a = HDotX / ax;
@@ -516,7 +523,7 @@ ERD float DisneyPdf(const HitData& hd, F3 V, F3 N, F3 L) {   // src/Disney.cpp:9
     float ax = maxf(0.001f, hd.roughness / aspect);
     float ay = maxf(0.001f, hd.roughness * aspect);
     float pdfGTR2_aniso = GTR2_aniso(NDotH, dot(H, T), dot(H, B), ax, ay) * NDotH;
-    float pdfGTR1 = GTR1(NDotH, clearcoatAlpha) * NDotH;
+    float pdfGTR1 = GTR1(NDotH, clearcoatAlpha, hd.gtr1_log) * NDotH;
     float ratio = 1.0f / (1.0f + hd.clearcoat);
     float pdfSpec = lerpf(pdfGTR1, pdfGTR2_aniso, ratio) / (4.0f * __builtin_fabsf(dot(L, H)));
     float pdfDiff = __builtin_fabsf(dot(L, N)) * (1.0f / PIF);
@@ -578,7 +585,7 @@ ERD F3 DisneyEval(const HitData& hd, F3 V, F3 N, F3 L) {   // src/Disney.cpp:160
         float Gs = SmithG_GGX_aniso(NDotL, dot(L, T), dot(L, B), ax, ay);
         Gs *= SmithG_GGX_aniso(NDotV, dot(V, T), dot(V, B), ax, ay);
         F3 Fsheen = FH * hd.sheen * Csheen;
-        float Dr = GTR1(NDotH, lerpf(0.1f, 0.001f, hd.clearcoatGloss));
+        float Dr = GTR1(NDotH, lerpf(0.1f, 0.001f, hd.clearcoatGloss), hd.gtr1_log);
         float Fr = lerpf(0.04f, 1.0f, FH);
         float Gr = SmithG_GGX(NDotL, 0.25f) * SmithG_GGX(NDotV, 0.25f);
         brdf = addf(((1.0f / PIF) * lerpf(Fd, ss, hd.subsurface) * Cdlin + Fsheen) * (1.0f - hd.metallic) + Gs * Fs * Ds,
@@ -610,8 +617,12 @@ ERD void generate_hit_data(const DevScene& S, const ErMaterial& mat, const HitFu
         F3 localNormal = (ncolor * 2) - f3s(1.0f);
         hd.normal = normalized(localNormal.x * hit.tangent - localNormal.y * hit.bitangent + localNormal.z * hit.normal);
     }
-    hd.roughness = ermath::er_pow(hd.roughness, 2.2f);
-    hd.metallic = ermath::er_pow(hd.metallic, 2.2f);
+    // roughness and metallic to the power 2.2 (src/kernel.cpp:152-153): of a constant channel once per material on the host, of a
+    // textured one here
+    const float4 pre = S.mat_pre[hit.material];
+    hd.roughness = mat.roughness_tex < 0 ? pre.x : ermath::er_pow(hd.roughness, 2.2f);
+    hd.metallic = mat.metallic_tex < 0 ? pre.y : ermath::er_pow(hd.metallic, 2.2f);
+    hd.gtr1_log = pre.w != 0.0f ? pre.z : __builtin_nanf("");
     hd.clearcoatGloss = mat.clearcoat_gloss;
     hd.clearcoat = mat.clearcoat;
     hd.anisotropic = mat.anisotropic;

@@ -171,6 +171,7 @@ struct ErScene {
     DevBuf<float4> d_nodes, d_nodes8, d_isect, d_attr, d_passes;
     DevBuf<float4> d_plane;      // staging: one pass gathered as a plane for er_read_pass
     DevBuf<ErMaterial> d_materials;
+    DevBuf<float4> d_mat_pre;    // DevScene::mat_pre
     DevBuf<ErPointLight> d_lights;
     DevBuf<DevTex> d_textures;
     DevBuf<float> d_tex_pool, d_cdf;
