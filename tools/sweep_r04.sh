@@ -3,7 +3,7 @@
 #   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU, fused schedule
 #   bash tools/sweep_r04.sh c4     -> C4: tracer/shader split, ring-visit and batch thresholds
 set -o pipefail
-what=${1:?sim8|c4|c4w|shares|knobs|retune}
+what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13}
 out=gpurun_out/sweep_r04_$what
 mkdir -p $out
 line() { python3 -c "
@@ -70,4 +70,17 @@ if [ "$what" = retune ]; then      # after -fno-slp-vectorize: the tracer / shad
   run c2_refill16 ER_STREAM_REFILL_MIN=16 -- --steps 20 --warmup 5
   run c2_batch48 ER_STREAM_BATCH_MIN=48 -- --steps 20 --warmup 5
   for s in 8; do run sim8_w12 ER_STREAM_WAVES=12 -- --sim-world 8 --steps 20 --warmup 5; run sim8_w16 ER_STREAM_WAVES=16 -- --sim-world 8 --steps 20 --warmup 5; done
+fi
+if [ "$what" = knobs13 ]; then      # C2 at 13 + 3 after the shader diet: thresholds again
+  S="--steps 20 --warmup 5"
+  run base X=1 -- $S
+  run refill8 ER_STREAM_REFILL_MIN=8 -- $S
+  run refill16 ER_STREAM_REFILL_MIN=16 -- $S
+  run refill20 ER_STREAM_REFILL_MIN=20 -- $S
+  run batch48 ER_STREAM_BATCH_MIN=48 -- $S
+  run batch32 ER_STREAM_BATCH_MIN=32 -- $S
+  run fin32 ER_STREAM_FIN_MIN=32 -- $S
+  run fin48 ER_STREAM_FIN_MIN=48 -- $S
+  run xcd0 ER_STREAM_XCD_TILES=0 -- $S
+  run base2 X=1 -- $S
 fi
