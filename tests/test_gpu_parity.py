@@ -487,3 +487,44 @@ def test_adaptive_tracer_shader_split_does_not_change_the_image(monkeypatch, cap
     assert len(lines) >= 3, err
     tracers = [int(l.split("->")[1].split("+")[0]) for l in lines if "->" in l]
     assert tracers and all(a >= b for a, b in zip(tracers, tracers[1:])) and min(tracers) >= 10 and max(tracers) <= 13, lines
+
+
+def test_host_precomputed_constants_equal_the_device_evaluation(monkeypatch):
+    """Round 4 moved three per-frame / per-material evaluations from every sample to the host (csrc/er_api.cpp), computed with the
+    same er_math.h functions the device calls: the camera's six rotation sines / cosines (src/kernel.cpp:371-473), pow(roughness, 2.2)
+    and pow(metallic, 2.2) of untextured channels (src/kernel.cpp:152-153) and the logarithm GTR1 takes (src/Disney.cpp:40-46); and
+    the texture wrap |x % w| became a mask when every texture has power-of-two sides.  Each has a knob that makes the device do the
+    work itself: the images must not differ in a single bit (rotated thin-lens camera, textured + constant materials, clearcoat)."""
+    sc = scenes.torture(3000, 96, 64, seed=5, n_materials=6, tex_size=16, hdri_size=(64, 32), n_lights=0)
+    sc.materials[1].roughness_tex = -1
+    sc.materials[1].metallic_tex = -1          # constant channels beside textured ones
+    sc.materials[1].roughness, sc.materials[1].metallic = 0.37, 0.62
+    sc.materials[2].clearcoat = 1.0
+    sc.materials[2].clearcoat_gloss = 0.3
+    sc.camera.bokeh = 1
+    sc.camera.focus_distance = 3.0
+    sc.camera.rotation = abi.ErVec3(3.0, -5.0, 2.0)
+    sc._desc = None
+    ref = gpu_render(sc, 5, max_bounces=8, flags=abi.FLAG_STREAM)
+    for knob in ("ER_CAM_TRIG_ON_DEVICE", "ER_MAT_PRE_ON_DEVICE", "ER_TEX_POW2"):
+        monkeypatch.setenv(knob, "0" if knob == "ER_TEX_POW2" else "1")
+        for flags in (abi.FLAG_STREAM, abi.FLAG_WAVEFRONT):
+            other = gpu_render(sc, 5, max_bounces=8, flags=flags)
+            for p in ("beauty", "normal", "tangent", "bitangent"):
+                assert (ref[p].view(np.uint32) == other[p].view(np.uint32)).all(), (knob, flags, p)
+            assert (ref["rng"] == other["rng"]).all(), (knob, flags)
+        monkeypatch.delenv(knob)
+
+
+def test_textures_and_hdri_without_power_of_two_sides_bit_exact(oracle_mod):
+    """The general texture wrap (a signed `%` by the run-time side, src/Texture.cpp:176-180) is what runs when ANY texture or the
+    HDRI has a side that is not a power of two (the mask form is only taken when all are): 12x10 textures, a 24x12 HDRI."""
+    sc = scenes.torture(2500, 80, 60, seed=9, n_materials=5, tex_size=16, hdri_size=(64, 32), n_lights=0)
+    r = scenes.Rand(77, 3)
+    sc.textures = [(abi._f32(r.u01(10, 12, 3)), 12, 10, 3, i % 2) for i in range(len(sc.textures))]      # (data [h, w, c], w, h, channels, filter)
+    sc.hdri = (abi._f32(0.2 + 2.0 * r.u01(12, 24, 3)), 24, 12, 3, 0)
+    sc._desc = None
+    g = gpu_render(sc, 4, max_bounces=8)
+    o = oracle_render(oracle_mod, sc, 4, max_bounces=8)
+    compare(g, o, what="non-power-of-two textures")
+    assert g["counters"]["bounce_samples"] == o["counters"]["bounce_samples"]
