@@ -3,7 +3,7 @@
 #   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU, fused schedule
 #   bash tools/sweep_r04.sh c4     -> C4: tracer/shader split, ring-visit and batch thresholds
 set -o pipefail
-what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13}
+what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13|diet}
 out=gpurun_out/sweep_r04_$what
 mkdir -p $out
 line() { python3 -c "
@@ -83,4 +83,17 @@ if [ "$what" = knobs13 ]; then      # C2 at 13 + 3 after the shader diet: thresh
   run fin48 ER_STREAM_FIN_MIN=48 -- $S
   run xcd0 ER_STREAM_XCD_TILES=0 -- $S
   run base2 X=1 -- $S
+fi
+if [ "$what" = diet ]; then      # the host-precomputed constants against their device evaluation, one library, alternating (knobs of er_api.cpp)
+  for i in 1 2; do
+    run c2_base_$i X=1 -- --steps 20 --warmup 5
+    run c2_cam_on_device_$i ER_CAM_TRIG_ON_DEVICE=1 -- --steps 20 --warmup 5
+    run c2_mat_on_device_$i ER_MAT_PRE_ON_DEVICE=1 -- --steps 20 --warmup 5
+    run c2_wrap_by_division_$i ER_TEX_POW2=0 -- --steps 20 --warmup 5
+    run c2_all_three_$i ER_CAM_TRIG_ON_DEVICE=1 ER_MAT_PRE_ON_DEVICE=1 ER_TEX_POW2=0 -- --steps 20 --warmup 5
+  done
+  run c5_base X=1 -- --config C5 --steps 12 --warmup 3
+  run c5_wrap_by_division ER_TEX_POW2=0 -- --config C5 --steps 12 --warmup 3
+  run c5_mat_on_device ER_MAT_PRE_ON_DEVICE=1 -- --config C5 --steps 12 --warmup 3
+  run c5_all_three ER_CAM_TRIG_ON_DEVICE=1 ER_MAT_PRE_ON_DEVICE=1 ER_TEX_POW2=0 -- --config C5 --steps 12 --warmup 3
 fi
