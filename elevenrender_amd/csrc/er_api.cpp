@@ -332,9 +332,9 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
         s->stream_blocks = (uint32_t)prop.multiProcessorCount;
-        // 12 tracer + 4 shader waves (shader waves at issue priority 1; finished and escaped paths handled in batches of their own,
-        // er_stream.hip); before: 11 + 5, round 2: 10 + 6.  With the point-light extension a shading step is a third longer (a second
-        // BRDF evaluation, a second shadow query): 11 + 5 there (C5: 1 188 vs 1 130 Msamples/s, profiles/r03_ab_split_by_config.log)
+        // The split between tracer and shader waves (shader waves at issue priority 1; finished and escaped paths handled in batches
+        // of their own, er_stream.hip).  Round 2: 10 + 6, round 3: 12 + 4 (11 + 5 with the point-light extension, whose shading
+        // step is a third longer); since round 4's shorter shading step:
         // 13 tracer + 3 shader waves where the shading step is at its cheapest -- plain materials, a scene that lives in the caches
         // (C2: 1 787 vs 1 715 Msamples/s at 12 + 4) -- and 12 + 4 where it costs more: textured materials (C5 without lights: 1 560 vs
         // 1 489 at 13 + 3), point lights (C5: 1 350 vs 1 234), or a scene beyond the Infinity Cache (C4, 10 M triangles: 1 562 vs 1 483)
