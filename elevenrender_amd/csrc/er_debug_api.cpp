@@ -40,6 +40,16 @@ static int er_debug_cdf_search_impl(const float* cdf, int length, const float* v
     return ER_OK;
 }
 
+static int er_debug_stream_deal_impl(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, int xcd_aware, uint32_t edge, uint32_t* out, uint32_t out_cap,
+                                     uint32_t* most) {
+    if ((count && !owned) || !tiles_x || !blocks || !most) return fail(ER_ERR_INVALID_ARG, "er_debug_stream_deal: bad argument");
+    std::vector<uint32_t> deal;
+    *most = er_stream_deal_tiles(owned, count, tiles_x, blocks, xcd_aware != 0, deal, edge);
+    if (deal.size() > out_cap || (deal.size() && !out)) return fail(ER_ERR_INVALID_ARG, "er_debug_stream_deal: out holds fewer than blocks * most entries");
+    for (size_t i = 0; i < deal.size(); i++) out[i] = deal[i];
+    return ER_OK;
+}
+
 static int er_debug_bvh_check_impl(const float* vertices, const float* normals, uint32_t tri_count, int threads, ErBvhCheck* out) {
     if (!out || (tri_count && (!vertices || !normals))) return fail(ER_ERR_INVALID_ARG, "er_debug_bvh_check: NULL argument");
     ErBvhBuild b;
@@ -251,6 +261,9 @@ extern "C" void er_debug_set_host_alloc_limit(uint64_t bytes) { g_host_alloc_lim
 extern "C" {
 int er_debug_closest_hit(ErScene* s, const float* origins, const float* dirs, uint32_t n, int32_t* tri_ids, float* positions, float* distances) { return guarded("er_debug_closest_hit", [&]() -> int { return er_debug_closest_hit_impl(s, origins, dirs, n, tri_ids, positions, distances); }); }
 int er_debug_cdf_search(const float* cdf, int length, const float* values, int32_t* out, int count) { return guarded("er_debug_cdf_search", [&]() -> int { return er_debug_cdf_search_impl(cdf, length, values, out, count); }); }
+int er_debug_stream_deal(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, int xcd_aware, uint32_t edge, uint32_t* out, uint32_t out_cap, uint32_t* most) {
+    return guarded("er_debug_stream_deal", [&]() -> int { return er_debug_stream_deal_impl(owned, count, tiles_x, blocks, xcd_aware, edge, out, out_cap, most); });
+}
 int er_debug_bvh_check(const float* vertices, const float* normals, uint32_t tri_count, int threads, ErBvhCheck* out) { return guarded("er_debug_bvh_check", [&]() -> int { return er_debug_bvh_check_impl(vertices, normals, tri_count, threads, out); }); }
 int er_debug_trace_rays(ErScene* s, const float* origins, const float* dirs, uint32_t n, const int32_t* self_slots, const float* limits, int32_t* tri_ids,
                         int32_t* slots, float* positions, float* distances, int32_t* info) {

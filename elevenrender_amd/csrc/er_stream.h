@@ -15,6 +15,11 @@ struct WfState;
                                   // rings of more slots take is worth more as tree levels)
 #endif
 
+#ifndef ER_STREAM_SUPER_TILE_DEFAULT
+#define ER_STREAM_SUPER_TILE_DEFAULT 8u   // side of the screen regions dealt whole to one XCD, in tiles.  16 is +1.6 % on C2, +5 % on C4, +2.5 % on C5
+                                          // (frames of even cost) and -8 ... -18 % on frames whose cost is uneven (the soup seen from far away / off
+                                          // to one side): fewer, larger regions per XCD sample the frame's cost too coarsely (profiles/r04_sweep_super_tile.log)
+#endif
 #ifndef ER_STREAM_SMALL_SHARE
 #define ER_STREAM_SMALL_SHARE 1152u  // owned pixels per CU up to which a workgroup runs as 12 waves of 168 registers (9 tracers + 3 shaders) instead of 16 of 128
 #endif
@@ -32,7 +37,8 @@ struct WfState;
 void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
                       uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, hipStream_t stream);
 // the deal of the owned tiles to the workgroups (device copy of `out` = `deal` above, deal_count = out.size()); returns the most tiles of one workgroup
-uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, bool xcd_aware, std::vector<uint32_t>& out);
+// edge: side of a super-tile in 8 x 8 tiles; 0 = ER_STREAM_SUPER_TILE from the environment, else ER_STREAM_SUPER_TILE_DEFAULT
+uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, bool xcd_aware, std::vector<uint32_t>& out, uint32_t edge = 0);
 uint32_t er_stream_record_bytes(bool lights);
 size_t er_stream_spill_entries(uint32_t blocks);
 hipError_t er_probe_stream(const char** which);

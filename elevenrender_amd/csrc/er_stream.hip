@@ -868,8 +868,12 @@ hipError_t er_probe_stream(const char** which) {
 // tiles are dealt round-robin to its workgroups: the camera rays and first bounces that an L2 serves then come from a few
 // compact screen regions instead of from every eighth tile of the whole frame.  out[b + k * blocks] = the k-th tile of
 // workgroup b, 0xFFFFFFFF = none; returns the largest number of tiles any workgroup got.
-uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, bool xcd_aware, std::vector<uint32_t>& out) {
-    static const uint32_t edge = [] { const char* e = getenv("ER_STREAM_SUPER_TILE"); int v = e ? atoi(e) : 8; return (uint32_t)(v < 1 ? 1 : v); }();   // (A/B knob)
+uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, bool xcd_aware, std::vector<uint32_t>& out, uint32_t edge) {
+    if (edge == 0u) {
+        const char* e = getenv("ER_STREAM_SUPER_TILE");      // (A/B knob)
+        const int v = e ? atoi(e) : 0;
+        edge = v >= 1 ? (uint32_t)v : ER_STREAM_SUPER_TILE_DEFAULT;
+    }
     const uint32_t X = (xcd_aware && blocks % 8u == 0u) ? 8u : 1u, per = blocks / X, S8 = edge;
     const uint32_t super_x = (tiles_x + S8 - 1u) / S8;
     std::map<uint32_t, std::vector<uint32_t>> by_super;      // row-major super-tile order; tiles inside keep their row-major order
@@ -882,6 +886,23 @@ uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t ti
         uint32_t best = 0;
         for (uint32_t x = 1; x < X; x++) if (seq[x].size() < seq[best].size()) best = x;
         seq[best].insert(seq[best].end(), kv.second.begin(), kv.second.end());
+    }
+    // Whole super-tiles leave the XCDs up to one super-tile apart (1.6 % of an XCD's share of a 1080p frame at the default edge, 6 % at
+    // 16) and a launch lasts as long as its fullest XCD: level them tile by tile -- the tail of the fullest XCD's last super-tile goes
+    // to the emptiest one -- until no two differ by more than a tile (tests/test_abi_cpu.py; within noise on the soup frames,
+    // profiles/r04_sweep_super_tile.log: what a larger super-tile loses on a frame of uneven cost is the CONTENT of its XCDs' shares).
+    const char* lv = getenv("ER_STREAM_LEVEL_XCDS");      // (A/B knob)
+    for (; !(lv && atoi(lv) == 0);) {
+        uint32_t hi = 0, lo = 0;
+        for (uint32_t x = 1; x < X; x++) {
+            if (seq[x].size() > seq[hi].size()) hi = x;
+            if (seq[x].size() < seq[lo].size()) lo = x;
+        }
+        const size_t diff = seq[hi].size() - seq[lo].size();
+        if (diff <= 1u) break;
+        const size_t n = diff / 2u;
+        seq[lo].insert(seq[lo].end(), seq[hi].end() - (ptrdiff_t)n, seq[hi].end());
+        seq[hi].resize(seq[hi].size() - n);
     }
     uint32_t maxk = 0;
     for (uint32_t x = 0; x < X; x++) maxk = std::max<uint32_t>(maxk, (uint32_t)((seq[x].size() + per - 1u) / per));

@@ -98,6 +98,13 @@ int er_debug_eval(struct ErScene* scene, int kind, const float* in, uint32_t n, 
 struct ErComm;
 int er_debug_comm_create_local(uint32_t world, struct ErComm** out);
 
+/* The streaming schedule's deal of a rank's owned 8 x 8 tiles (`owned`: tile indices ty * tiles_x + tx) to `blocks` workgroups, as
+ * er_render_begin makes it (host code, no device needed): out[b + k * blocks] = the k-th tile of workgroup b or 0xFFFFFFFF, for
+ * k < *most; workgroups b and b + 8 share an XCD.  edge = side of a super-tile in tiles, 0 = the library's default.  out_cap >= blocks * *most
+ * (a first call with out_cap = 0 fails with ER_ERR_INVALID_ARG after setting *most). */
+int er_debug_stream_deal(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, int xcd_aware, uint32_t edge, uint32_t* out, uint32_t out_cap,
+                         uint32_t* most);
+
 /* Test hook for the out-of-memory path of the boundary: while `bytes` is non-zero, any single large host allocation the
  * library announces (scene copy in er_scene_create, build staging in er_render_begin) larger than `bytes` fails as
  * std::bad_alloc would, which the entry point must turn into ER_ERR_OOM (no exception crosses the C ABI).  0 = off. */

@@ -216,3 +216,45 @@ def test_no_instruction_touches_a_load_destination_between_its_issue_and_its_wai
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "check_split_wait.py"), asm[0]], capture_output=True, text=True)
     assert p.returncode == 0, p.stdout[-3000:]
     assert "8 split-wait sites, 0 offending instructions" in p.stdout      # 4 instantiations x 2 wave counts
+
+
+def stream_deal(owned, tiles_x, blocks=256, xcd_aware=1, edge=0):
+    lib = abi.load()
+    U = C.POINTER(C.c_uint32)
+    lib.er_debug_stream_deal.argtypes = [U, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, U, C.c_uint32, U]
+    lib.er_debug_stream_deal.restype = C.c_int
+    owned = np.ascontiguousarray(owned, np.uint32)
+    most = C.c_uint32()
+    assert lib.er_debug_stream_deal(owned.ctypes.data_as(U), len(owned), tiles_x, blocks, xcd_aware, edge, None, 0, C.byref(most)) == (abi.ER_ERR_INVALID_ARG if len(owned) else abi.ER_OK)
+    out = np.zeros(blocks * most.value, np.uint32)
+    assert lib.er_debug_stream_deal(owned.ctypes.data_as(U), len(owned), tiles_x, blocks, xcd_aware, edge, out.ctypes.data_as(U), len(out), C.byref(most)) == abi.ER_OK
+    return out.reshape(most.value, blocks)          # [k, b] = the k-th tile of workgroup b
+
+
+@pytest.mark.parametrize("edge", [0, 1, 8, 16, 32, 100])
+@pytest.mark.parametrize("frame", [(240, 135, 1, 0), (480, 270, 1, 0), (240, 135, 8, 3), (37, 5, 1, 0), (240, 135, 128, 37)])
+def test_stream_deal_is_a_levelled_partition_of_the_owned_tiles(frame, edge):
+    """The streaming schedule's deal of tiles to workgroups (er_stream.hip er_stream_deal_tiles; host code): every owned tile goes to
+    exactly one workgroup, the eight XCDs (workgroups b, b + 8, ...) get tile counts that differ by at most one whatever the
+    super-tile edge (round 4: whole super-tiles had left them up to one super-tile apart, and a launch lasts as long as its fullest
+    XCD), and the workgroups of an XCD differ by at most one tile."""
+    tiles_x, tiles_y, world, rank = frame
+    t = np.arange(tiles_x * tiles_y, dtype=np.uint32)
+    owned = t[((t % tiles_x) + (t // tiles_x)) % world == rank]          # the library's sharding: (tx + ty) % world
+    deal = stream_deal(owned, tiles_x, edge=edge)
+    got = deal[deal != 0xFFFFFFFF]
+    assert len(got) == len(owned) and (np.sort(got) == owned).all()
+    per_wg = (deal != 0xFFFFFFFF).sum(0)
+    per_xcd = per_wg.reshape(-1, 8).sum(0)
+    assert per_xcd.max() - per_xcd.min() <= 1, per_xcd
+    for x in range(8):
+        w = per_wg[x::8]
+        assert w.max() - w.min() <= 1, (x, w)
+    assert per_wg.max() == deal.shape[0]
+    # super-tile locality: with the default edge the tiles of an XCD come from far fewer super-tiles than a round-robin deal would touch
+    if edge == 0 and world == 1 and tiles_x >= 240:
+        e = 8
+        sup = lambda tiles: len(np.unique((tiles // tiles_x // e) * ((tiles_x + e - 1) // e) + (tiles % tiles_x) // e))
+        x0 = deal[:, 0::8]
+        n_super_total = sup(owned)
+        assert sup(x0[x0 != 0xFFFFFFFF]) <= n_super_total // 8 + 8

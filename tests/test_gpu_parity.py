@@ -528,3 +528,19 @@ def test_textures_and_hdri_without_power_of_two_sides_bit_exact(oracle_mod):
     o = oracle_render(oracle_mod, sc, 4, max_bounces=8)
     compare(g, o, what="non-power-of-two textures")
     assert g["counters"]["bounce_samples"] == o["counters"]["bounce_samples"]
+
+
+def test_frame_wider_than_the_streaming_schedules_packed_pixel(oracle_mod):
+    """The streaming schedule carries a pixel as x | y << 16 (round 4), so it takes frames up to 65 535 x 65 535.  A 65 600 x 3 frame
+    (196 800 pixels: a size at which flags = 0 would otherwise choose it) must be rendered by the automatic choice with another
+    schedule, bit-exact against the oracle like every other frame, and forcing ER_FLAG_STREAM on it must be refused with
+    ER_ERR_INVALID_ARG rather than wrap a coordinate."""
+    sc = scenes.soup(300, 65600, 3, seed=31, hdri_size=(64, 32))
+    g = gpu_render(sc, 2, max_bounces=4)
+    o = oracle_render(oracle_mod, sc, 2, max_bounces=4)
+    compare(g, o, what="65600 x 3 frame, automatic schedule")
+    rm = render.RenderingManager(render.RenderParameters(max_bounces=4, flags=abi.FLAG_STREAM))
+    with pytest.raises(abi.ErError) as e:
+        rm.start_rendering(sc)
+    assert e.value.code == abi.ER_ERR_INVALID_ARG and "65535" in str(e.value)
+    rm.close()

@@ -3,7 +3,7 @@
 #   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU, fused schedule
 #   bash tools/sweep_r04.sh c4     -> C4: tracer/shader split, ring-visit and batch thresholds
 set -o pipefail
-what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13|diet}
+what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13|diet|supertile|supertile2|supertile3|level}
 out=gpurun_out/sweep_r04_$what
 mkdir -p $out
 line() { python3 -c "
@@ -96,4 +96,35 @@ if [ "$what" = diet ]; then      # the host-precomputed constants against their 
   run c5_wrap_by_division ER_TEX_POW2=0 -- --config C5 --steps 12 --warmup 3
   run c5_mat_on_device ER_MAT_PRE_ON_DEVICE=1 -- --config C5 --steps 12 --warmup 3
   run c5_all_three ER_CAM_TRIG_ON_DEVICE=1 ER_MAT_PRE_ON_DEVICE=1 ER_TEX_POW2=0 -- --config C5 --steps 12 --warmup 3
+fi
+if [ "$what" = supertile ]; then      # edge of the per-XCD super-tile (in 8 x 8 tiles) on the 4K frame and on C2
+  for t in 8 4 16 32; do run c4_st$t ER_STREAM_SUPER_TILE=$t -- --config C4 --steps 6 --warmup 2; done
+  for t in 8 4 16; do run c2_st$t ER_STREAM_SUPER_TILE=$t -- --steps 20 --warmup 5; done
+  run c4_roundrobin ER_STREAM_XCD_TILES=0 -- --config C4 --steps 6 --warmup 2
+fi
+if [ "$what" = supertile2 ]; then      # finer: C2, C4, C5, one GPU's eighth
+  for t in 8 12 16 20 24 32 48; do run c2_st$t ER_STREAM_SUPER_TILE=$t -- --steps 20 --warmup 5; done
+  for t in 16 24 32 48 64; do run c4_st$t ER_STREAM_SUPER_TILE=$t -- --config C4 --steps 6 --warmup 2; done
+  for t in 8 16 24 32; do run c5_st$t ER_STREAM_SUPER_TILE=$t -- --config C5 --steps 12 --warmup 3; done
+  for t in 8 16 32; do run sim8_st$t ER_STREAM_SUPER_TILE=$t -- --sim-world 8 --steps 20 --warmup 5; done
+  for t in 8 16 32; do run sim2_st$t ER_STREAM_SUPER_TILE=$t -- --sim-world 2 --steps 20 --warmup 5; done
+fi
+if [ "$what" = supertile3 ]; then      # after the deal levels the XCDs tile by tile
+  for t in 8 16 24 32 48 64; do run c2_st$t ER_STREAM_SUPER_TILE=$t -- --steps 20 --warmup 5; done
+  for t in 8 16 32 48 64 96; do run c4_st$t ER_STREAM_SUPER_TILE=$t -- --config C4 --steps 6 --warmup 2; done
+  for t in 8 16 32 64; do run c5_st$t ER_STREAM_SUPER_TILE=$t -- --config C5 --steps 12 --warmup 3; done
+  for t in 8 16 32; do run sim8_st$t ER_STREAM_SUPER_TILE=$t -- --sim-world 8 --steps 20 --warmup 5; done
+  for t in 8 16 32; do run sim2_st$t ER_STREAM_SUPER_TILE=$t -- --sim-world 2 --steps 20 --warmup 5; done
+fi
+if [ "$what" = level ]; then      # the deal's tile-by-tile levelling of the XCDs on / off at the default super-tile edge and at 16
+  for i in 1 2 3; do
+    run c2_level_$i X=1 -- --steps 20 --warmup 5
+    run c2_nolevel_$i ER_STREAM_LEVEL_XCDS=0 -- --steps 20 --warmup 5
+  done
+  for i in 1 2; do
+    run c2_st16_level_$i ER_STREAM_SUPER_TILE=16 -- --steps 20 --warmup 5
+    run c2_st16_nolevel_$i ER_STREAM_SUPER_TILE=16 ER_STREAM_LEVEL_XCDS=0 -- --steps 20 --warmup 5
+  done
+  run c4_level X=1 -- --config C4 --steps 6 --warmup 2
+  run c4_nolevel ER_STREAM_LEVEL_XCDS=0 -- --config C4 --steps 6 --warmup 2
 fi
