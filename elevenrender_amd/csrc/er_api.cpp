@@ -359,18 +359,36 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         if (const char* e = getenv("ER_STREAM_ADAPT")) s->stream_adapt = atoi(e) != 0;
         const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
         if ((rc = upload(s->d_wf4, nullptr, slots * er_stream_record_bytes(lights_on) / sizeof(float4), s->stream)) != ER_OK) return rc;
-        if ((rc = upload(s->d_wf1, nullptr, 6, s->stream)) != ER_OK) return rc;        // [1] status word, [2..5] the tracers' lane occupancy
+        if ((rc = upload(s->d_wf1, nullptr, 24, s->stream)) != ER_OK) return rc;       // [1] status word, [2..5] the tracers' lane occupancy, [6..23] start / end per XCD
         if ((rc = upload(s->d_spill, nullptr, er_stream_spill_entries(s->stream_blocks), s->stream)) != ER_OK) return rc;
         s->stream_ctl = s->d_wf1.p;
         s->stream_lights = lights_on;
-        HIP_TRY(hipMemsetAsync(s->stream_ctl, 0, 6 * sizeof(uint32_t), s->stream));
+        HIP_TRY(hipMemsetAsync(s->stream_ctl, 0, 24 * sizeof(uint32_t), s->stream));
         // the workgroups' pixel rings: (pixel, samples left) entries, one per pixel of the workgroup's share
         // (capacity rounded up to a power of two: positions are monotonic 32-bit counters and may wrap)
         // (no minimum beyond one tile: a producer that comes round to a cell whose entry has not been read yet waits for its
         // reader, er_ring.h -- round 2 relied on "a lap of >= 4096 cells takes longer than a read")
         std::vector<uint32_t> deal;
         const bool xcd_aware = stream_xcd_aware(owned.size(), s->stream_blocks);
-        const uint32_t most = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), (s->x_res + ER_TILE - 1) / ER_TILE, s->stream_blocks, xcd_aware, deal);
+        const uint32_t tiles_x = (s->x_res + ER_TILE - 1) / ER_TILE;
+        uint32_t most = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), tiles_x, s->stream_blocks, xcd_aware, deal);
+        s->stream_deal_off = 0; s->stream_deal_n = (uint32_t)deal.size();
+        s->stream_deal_alt_off = 0; s->stream_deal_alt_n = 0;
+        s->stream_xcd_spread = -1.0;
+        // Larger screen regions per XCD are faster where a frame's cost is even and slower where it is not (er_stream.h), and only the run
+        // can tell which: with the knob unset a render starts on the deal of ER_STREAM_SUPER_TILE_LARGE and keeps the default edge's deal
+        // beside it in d_deal; er_stream_adapt switches to that one, for good, after a call whose XCDs finished too far apart.
+        const char* adapt_knob = getenv("ER_STREAM_ADAPT");
+        if (xcd_aware && s->stream_blocks % 8u == 0u && owned.size() * 64 / s->stream_blocks >= 4u * ER_STREAM_SLOTS && !(p->flags & ER_FLAG_COUNTERS) &&
+            !getenv("ER_STREAM_SUPER_TILE") && !(adapt_knob && atoi(adapt_knob) == 0)) {
+            std::vector<uint32_t> large;
+            const uint32_t most_large = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), tiles_x, s->stream_blocks, xcd_aware, large, ER_STREAM_SUPER_TILE_LARGE);
+            s->stream_deal_alt_off = (uint32_t)large.size(); s->stream_deal_alt_n = (uint32_t)deal.size();
+            s->stream_deal_n = (uint32_t)large.size();
+            large.insert(large.end(), deal.begin(), deal.end());
+            deal.swap(large);
+            most = std::max(most, most_large);
+        }
         if ((rc = upload(s->d_deal, deal.data(), deal.size(), s->stream)) != ER_OK) return rc;
         HIP_TRY(hipStreamSynchronize(s->stream));          // (`deal` goes out of scope)
         if (s->x_res > 65535u || s->y_res > 65535u)
@@ -545,8 +563,9 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     if (s->params.flags & ER_FLAG_FUSED) {
         er_launch_fused(s->dev, s->d_ticket.p, s->d_spill.p, n, count, s->fused_blocks, s->stream);
     } else if (s->params.flags & ER_FLAG_STREAM) {
-        HIP_TRY(hipMemsetAsync(s->stream_ctl + 2, 0, 4 * sizeof(uint32_t), s->stream));      // the call's lane-occupancy counts
-        er_launch_stream(s->dev, s->d_dev.p, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_deal.p, (uint32_t)s->d_deal.n, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
+        HIP_TRY(hipMemsetAsync(s->stream_ctl + 2, 0, 22 * sizeof(uint32_t), s->stream));      // the call's lane-occupancy counts, its end per XCD ...
+        HIP_TRY(hipMemsetAsync(s->stream_ctl + 6, 0xFF, 2 * sizeof(uint32_t), s->stream));    // ... and its start (a minimum)
+        er_launch_stream(s->dev, s->d_dev.p, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_deal.p + s->stream_deal_off, s->stream_deal_n, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
                          s->stream_blocks, s->stream_tracers, s->stream_waves, s->stream);
     } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
         er_launch_render(s->dev, n, count, s->stream);
@@ -613,12 +632,18 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
 // for a finished one.  The word stays set until the next er_render_begin.
 int er_scene_stream_status(ErScene* s, const char* who) {
     if (!(s->params.flags & ER_FLAG_STREAM) || !s->stream_ctl) return ER_OK;
-    uint32_t st[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t st[24] = {0};
     HIP_TRY(hipMemcpy(st, s->stream_ctl, sizeof(st), hipMemcpyDeviceToHost));
     if (st[1] != 0)
         return fail(ER_ERR_STATE, std::string(who) + ": the streaming schedule stopped without finishing (watchdog status " + std::to_string(st[1]) + "); the planes are incomplete");
     const unsigned long long iters = (unsigned long long)st[2] | ((unsigned long long)st[3] << 32), busy = (unsigned long long)st[4] | ((unsigned long long)st[5] << 32);
     s->stream_busy = iters ? (double)busy / (64.0 * (double)iters) : 0.0;
+    // how far apart the XCDs finished, as a share of the launch (100 MHz ticks; a launch under 2 ms says nothing: start-up and tail)
+    auto u64 = [&](int i) { return (unsigned long long)st[i] | ((unsigned long long)st[i + 1] << 32); };
+    const unsigned long long t0 = u64(6);
+    unsigned long long lo = ~0ull, hi = 0;
+    for (int x = 0; x < 8; x++) { const unsigned long long e = u64(8 + 2 * x); lo = std::min(lo, e); hi = std::max(hi, e); }
+    s->stream_xcd_spread = (t0 != ~0ull && lo > t0 && hi - t0 >= 200000ull) ? (double)(hi - lo) / (double)(hi - t0) : -1.0;
     return ER_OK;
 }
 
@@ -632,6 +657,17 @@ int er_scene_stream_status(ErScene* s, const char* who) {
 static void er_stream_adapt(ErScene* s) {
     const bool verbose = getenv("ER_STREAM_VERBOSE") != nullptr;      // (read per call: a test turns it on for one render)
     if (verbose && (s->params.flags & ER_FLAG_STREAM) && !s->stream_adapt) fprintf(stderr, "[er_stream] tracer lanes %.3f full at %u + %u waves (fixed split)\n", s->stream_busy, s->stream_tracers, s->stream_waves - s->stream_tracers);
+    // the deal: large screen regions per XCD only while the XCDs finish together (er_stream.h, er_render_begin)
+    if ((s->params.flags & ER_FLAG_STREAM) && s->stream_deal_alt_n && s->stream_xcd_spread >= 0.0) {
+        if (verbose) fprintf(stderr, "[er_stream] XCDs finished %.3f of the launch apart on super-tiles of %u%s\n", s->stream_xcd_spread, (unsigned)ER_STREAM_SUPER_TILE_LARGE,
+                             s->stream_xcd_spread > ER_STREAM_XCD_SPREAD_MAX ? " -> the default deal" : "");
+        if (s->stream_xcd_spread > ER_STREAM_XCD_SPREAD_MAX) {
+            s->stream_deal_off = s->stream_deal_alt_off; s->stream_deal_n = s->stream_deal_alt_n;
+            s->stream_deal_alt_n = 0;
+        }
+    } else if (verbose && (s->params.flags & ER_FLAG_STREAM) && s->stream_xcd_spread >= 0.0) {
+        fprintf(stderr, "[er_stream] XCDs finished %.3f of the launch apart (fixed deal)\n", s->stream_xcd_spread);
+    }
     if (!s->stream_adapt || !(s->params.flags & ER_FLAG_STREAM) || s->stream_busy <= 0.0) return;
     const uint32_t lo = s->stream_waves == 12 ? 7u : 10u;
     const uint32_t before = s->stream_tracers;

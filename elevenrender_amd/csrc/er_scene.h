@@ -185,9 +185,12 @@ struct ErScene {
     uint32_t fused_blocks = 0;
     uint32_t stream_blocks = 0, stream_tracers = 0, stream_waves = 16, stream_ring_cap = 0;     // streaming schedule (er_stream.hip): workgroups; tracer waves of the 16
     bool stream_lights = false;                         //   slot records carry the point-light query's line
-    uint32_t* stream_ctl = nullptr;                     //   [0] pixel ticket, [1] status word, [2..3] tracer iterations, [4..5] busy tracer lanes of the last call
+    uint32_t* stream_ctl = nullptr;                     //   [0] pixel ticket, [1] status word, [2..3] tracer iterations, [4..5] busy tracer lanes of the last call, [6..7] its start, [8..23] its end per XCD (100 MHz)
     bool stream_adapt = false;                          //   move a wave between the roles by how full the tracer lanes were (er_stream_adapt)
     double stream_busy = 0.0;                           //   tracer lanes that held a ray, last completed call
+    uint32_t stream_deal_off = 0, stream_deal_n = 0;    //   the deal in use inside d_deal (entries): the one of large super-tiles first, the default edge's after it
+    uint32_t stream_deal_alt_off = 0, stream_deal_alt_n = 0;   //   the fallback deal (0 entries: none), taken when the XCDs of a call finished too far apart
+    double stream_xcd_spread = 0.0;                     //   (latest - earliest XCD) / launch duration of the last completed call; < 0: not measured
     std::vector<WfState> wf;              // slot pools (see er_render_begin)
     std::vector<hipStream_t> pool_streams;   // pool 0 runs on `stream`, pool p > 0 on pool_streams[p - 1]
     std::vector<hipEvent_t> pool_events;     // [0] fork; [p] pool p has finished

@@ -16,9 +16,16 @@ struct WfState;
 #endif
 
 #ifndef ER_STREAM_SUPER_TILE_DEFAULT
-#define ER_STREAM_SUPER_TILE_DEFAULT 8u   // side of the screen regions dealt whole to one XCD, in tiles.  16 is +1.6 % on C2, +5 % on C4, +2.5 % on C5
-                                          // (frames of even cost) and -8 ... -18 % on frames whose cost is uneven (the soup seen from far away / off
-                                          // to one side): fewer, larger regions per XCD sample the frame's cost too coarsely (profiles/r04_sweep_super_tile.log)
+#define ER_STREAM_SUPER_TILE_DEFAULT 8u   // side of the screen regions dealt whole to one XCD, in tiles: the deal that spreads a frame's cost evenly
+#endif
+#ifndef ER_STREAM_SUPER_TILE_LARGE
+#define ER_STREAM_SUPER_TILE_LARGE 16u    // the deal a render STARTS with: an XCD's 512 tiles in flight are two compact regions instead of eight, +1.6 % on C2, +5 % on
+                                          // C4, +2.5 % on C5 (frames of even cost) -- and -8 ... -18 % on frames whose cost is uneven (the soup seen from far away / off
+                                          // to one side: fewer, larger regions per XCD sample the cost too coarsely), so the library keeps it only while the XCDs of a
+                                          // call finish within ER_STREAM_XCD_SPREAD_MAX of each other (er_api.cpp er_stream_adapt; profiles/r04_sweep_super_tile.log)
+#endif
+#ifndef ER_STREAM_XCD_SPREAD_MAX
+#define ER_STREAM_XCD_SPREAD_MAX 0.10     // (measured: 0.02 ... 0.09 on every deal of every frame tried -- the XCDs never finish together -- 0.15 and 0.32 on large regions of uneven cost)
 #endif
 #ifndef ER_STREAM_SMALL_SHARE
 #define ER_STREAM_SMALL_SHARE 1152u  // owned pixels per CU up to which a workgroup runs as 12 waves of 168 registers (9 tracers + 3 shaders) instead of 16 of 128
@@ -30,9 +37,10 @@ struct WfState;
 // records: slots * er_stream_record_bytes(lights) bytes (slots = blocks * ER_STREAM_SLOTS; lights: the scene uses the point-light
 // extension, whose queries take a third line per slot); spill: er_stream_spill_entries(blocks) uint2 entries; ring:
 // blocks * ring_cap uint2 entries (the workgroups' pixel rings; ring_cap = a power of two >= 64 * er_stream_deal_tiles(...) and
-// <= ER_STREAM_MAX_RING); status: five words at an address that is 4 (mod 8): [0] 0 unless a wave's watchdog or a ring guard fired,
+// <= ER_STREAM_MAX_RING); status: 23 words at an address that is 4 (mod 8): [0] 0 unless a wave's watchdog or a ring guard fired,
 // [1..2] iterations of all tracer waves' loops and [3..4] the lanes that held a ray in them, both added up as 64-bit counts by the
-// launch (the caller zeroes them before it).
+// launch (the caller zeroes them before it); [5..6] the earliest start of a workgroup (caller: all ones) and [7 + 2 x ..] the latest end of
+// a wave of XCD x = workgroup index % 8 (caller: zero), wall_clock64() ticks.
 // S_dev: a device copy of S (the kernel reads the scene descriptor from constant memory, not from its arguments).
 void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
                       uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, hipStream_t stream);

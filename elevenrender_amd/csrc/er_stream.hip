@@ -284,6 +284,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     // The scene descriptor lives in constant memory and is read with scalar loads where it is used.  As a by-value kernel argument its
     // ~60 dwords stayed in SGPRs for the whole kernel and the shading step moved 585 scalar spills to and from VGPR lanes (round 4).
     const DevScene& S = *(const DevScene*)Sp;
+    // when the launch began and when each XCD's last wave left (status[5..6], status[7 + 2 x ..]; 100 MHz): how evenly the deal spread
+    // the frame's COST over the XCDs is something only the run can tell (er_api.cpp er_stream_adapt)
+    if (threadIdx.x == 0) atomicMin((unsigned long long*)(status + 5), (unsigned long long)wall_clock64());
     constexpr uint32_t RQ_LOG2 = ST_RQ_LOG2, SLOTS = ER_STREAM_SLOTS, TOP_NODES = ER_STREAM_TOP_NODES;
     __shared__ uint32_t s_rq[1u << RQ_LOG2];
     __shared__ uint32_t s_sq[1u << ST_SQ_LOG2];
@@ -838,6 +841,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     unsigned t5 = 0, t6 = 0, t7 = 0;
     if (COUNT) { t5 = st_wave_sum(c_nodes); t6 = st_wave_sum(c_tris); t7 = st_wave_sum(c_texels); }
     if (lane == 0) {
+        atomicMax((unsigned long long*)(status + 7 + 2 * (blockIdx.x & 7u)), (unsigned long long)wall_clock64());
         if (t0) atomicAdd(&S.counters->paths, (unsigned long long)t0);
         if (t1) atomicAdd(&S.counters->bounce_samples, (unsigned long long)t1);
         if (t2) atomicAdd(&S.counters->rays, (unsigned long long)t2);

@@ -544,3 +544,31 @@ def test_frame_wider_than_the_streaming_schedules_packed_pixel(oracle_mod):
         rm.start_rendering(sc)
     assert e.value.code == abi.ER_ERR_INVALID_ARG and "65535" in str(e.value)
     rm.close()
+
+
+def test_deal_falls_back_when_the_xcds_finish_apart_and_the_image_does_not_change(monkeypatch, capfd):
+    """The streaming schedule starts a render on a deal of 16 x 16-tile screen regions per XCD (better L2 locality) and keeps the default
+    8 x 8 deal beside it; the kernel stamps when each XCD's last wave left, and after a call whose XCDs finished more than
+    ER_STREAM_XCD_SPREAD_MAX of the launch apart the library switches to the default deal for good (csrc/er_api.cpp er_stream_adapt,
+    csrc/er_stream.h).  A soup seen from far away -- geometry in the middle of the frame, sky around it -- is such a frame: the verbose
+    line must show the switch after the first call, and the planes of the three calls must equal those of the fixed default deal and of
+    the fixed large one bit for bit (any deal renders the same pixels)."""
+    sc = scenes.soup(60_000, 1280, 832, seed=31, hdri_size=(256, 128))
+    sc.camera.position = abi.ErVec3(0.01, 0.02, -3.0)
+    sc._desc = None
+    monkeypatch.setenv("ER_STREAM_SUPER_TILE", "8")
+    fixed8 = gpu_render(sc, 12, max_bounces=8, flags=abi.FLAG_STREAM, chunks=[8, 2, 2])
+    monkeypatch.setenv("ER_STREAM_SUPER_TILE", "16")
+    fixed16 = gpu_render(sc, 12, max_bounces=8, flags=abi.FLAG_STREAM, chunks=[8, 2, 2])
+    monkeypatch.delenv("ER_STREAM_SUPER_TILE")
+    monkeypatch.setenv("ER_STREAM_VERBOSE", "1")
+    capfd.readouterr()
+    auto = gpu_render(sc, 12, max_bounces=8, flags=abi.FLAG_STREAM, chunks=[8, 2, 2])
+    err = capfd.readouterr().err
+    for other in (fixed16, auto):
+        for p in ("beauty", "normal", "tangent", "bitangent"):
+            assert (fixed8[p].view(np.uint32) == other[p].view(np.uint32)).all(), p
+        assert (fixed8["rng"] == other["rng"]).all() and (fixed8["samples"] == other["samples"]).all()
+    lines = [l for l in err.splitlines() if l.startswith("[er_stream] XCDs finished")]
+    assert lines and "super-tiles of 16 -> the default deal" in lines[0], err
+    assert all("(fixed deal)" in l for l in lines[1:]), lines

@@ -36,7 +36,10 @@ def main():
     cases.append(("C1 Cornell box at 1920x1080", scenes.cornell(1920, 1080), 5))
     for name, sc, mb in cases:
         for e in edges:
-            os.environ["ER_STREAM_SUPER_TILE"] = str(e)
+            if e > 0:
+                os.environ["ER_STREAM_SUPER_TILE"] = str(e)
+            else:
+                os.environ.pop("ER_STREAM_SUPER_TILE", None)      # 0 = the library's own choice
             ms, n = ms_per_pass(sc, mb)
             print(f"{name}: edge {e}: {ms:.3f} ms per pass, {n} bounce samples in all", flush=True)
 

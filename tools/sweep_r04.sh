@@ -3,7 +3,7 @@
 #   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU, fused schedule
 #   bash tools/sweep_r04.sh c4     -> C4: tracer/shader split, ring-visit and batch thresholds
 set -o pipefail
-what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13|diet|supertile|supertile2|supertile3|level}
+what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13|diet|supertile|supertile2|supertile3|level|edgeauto}
 out=gpurun_out/sweep_r04_$what
 mkdir -p $out
 line() { python3 -c "
@@ -127,4 +127,17 @@ if [ "$what" = level ]; then      # the deal's tile-by-tile levelling of the XCD
   done
   run c4_level X=1 -- --config C4 --steps 6 --warmup 2
   run c4_nolevel ER_STREAM_LEVEL_XCDS=0 -- --config C4 --steps 6 --warmup 2
+fi
+if [ "$what" = edgeauto ]; then      # the deal that starts on 16 x 16-tile regions and falls back by the XCDs' measured finish times, against the fixed default edge
+  show() { grep -h "XCDs finished" $out/$1.err | sed 's/^/   /'; }
+  for i in 1 2; do
+    run c2_auto_$i ER_STREAM_VERBOSE=1 -- --steps 20 --warmup 5; show c2_auto_$i
+    run c2_edge8_$i ER_STREAM_VERBOSE=1 ER_STREAM_SUPER_TILE=8 -- --steps 20 --warmup 5; show c2_edge8_$i
+  done
+  run c4_auto ER_STREAM_VERBOSE=1 -- --config C4 --steps 6 --warmup 2; show c4_auto
+  run c4_edge8 ER_STREAM_VERBOSE=1 ER_STREAM_SUPER_TILE=8 -- --config C4 --steps 6 --warmup 2; show c4_edge8
+  run c5_auto ER_STREAM_VERBOSE=1 -- --config C5 --steps 12 --warmup 3; show c5_auto
+  run c5_edge8 ER_STREAM_VERBOSE=1 ER_STREAM_SUPER_TILE=8 -- --config C5 --steps 12 --warmup 3; show c5_edge8
+  run c5nl_auto ER_STREAM_VERBOSE=1 -- --config C5 --no-lights --steps 12 --warmup 3; show c5nl_auto
+  run sim2_auto ER_STREAM_VERBOSE=1 -- --sim-world 2 --steps 20 --warmup 5; show sim2_auto
 fi
