@@ -7,6 +7,8 @@ different winner); such pixels must stay within the image tolerance of SURVEY 8c
 (|d| <= 1e-3 + 1e-3|ref|) -- and must be rare.  Against the oracle in libm mode (what a CPU
 build of the reference computes) the image tolerance alone applies.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -486,7 +488,8 @@ def test_adaptive_tracer_shader_split_does_not_change_the_image(monkeypatch, cap
     lines = [l for l in err.splitlines() if l.startswith("[er_stream] tracer lanes")]
     assert len(lines) >= 3, err
     tracers = [int(l.split("->")[1].split("+")[0]) for l in lines if "->" in l]
-    assert tracers and all(a >= b for a, b in zip(tracers, tracers[1:])) and min(tracers) >= 10 and max(tracers) <= 13, lines
+    lo, hi = (7, 11) if os.environ.get("ER_STREAM_WAVES") == "12" else (10, 13)      # (tools/knob_corners.sh runs this file at 12 waves per CU too)
+    assert tracers and all(a >= b for a, b in zip(tracers, tracers[1:])) and min(tracers) >= lo and max(tracers) <= hi, lines
 
 
 def test_host_precomputed_constants_equal_the_device_evaluation(monkeypatch):
