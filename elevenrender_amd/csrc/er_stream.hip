@@ -868,7 +868,8 @@ hipError_t er_probe_stream(const char** which) {
 
 // Which workgroup renders which tiles.  Workgroups b and b + 8 run on the same XCD and share its 4 MB L2 (observed dispatch
 // order, MI355X_MICROARCH.md; used for speed only -- any deal gives the same pixels), so the frame is cut into super-tiles of
-// 8 x 8 tiles (64 x 64 pixels), every super-tile goes to ONE XCD (the one with the fewest tiles so far), and inside an XCD the
+// edge x edge tiles (8: 64 x 64 pixels; er_render_begin also makes the deal of 16, er_stream.h), every super-tile goes to ONE XCD (the
+// one with the fewest tiles so far), the XCDs are then levelled tile by tile, and inside an XCD the
 // tiles are dealt round-robin to its workgroups: the camera rays and first bounces that an L2 serves then come from a few
 // compact screen regions instead of from every eighth tile of the whole frame.  out[b + k * blocks] = the k-th tile of
 // workgroup b, 0xFFFFFFFF = none; returns the largest number of tiles any workgroup got.
