@@ -383,11 +383,13 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             !getenv("ER_STREAM_SUPER_TILE") && !(adapt_knob && atoi(adapt_knob) == 0)) {
             std::vector<uint32_t> large;
             const uint32_t most_large = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), tiles_x, s->stream_blocks, xcd_aware, large, ER_STREAM_SUPER_TILE_LARGE);
-            s->stream_deal_alt_off = (uint32_t)large.size(); s->stream_deal_alt_n = (uint32_t)deal.size();
-            s->stream_deal_n = (uint32_t)large.size();
-            large.insert(large.end(), deal.begin(), deal.end());
-            deal.swap(large);
-            most = std::max(most, most_large);
+            if ((size_t)most_large * 64u <= ER_STREAM_MAX_RING) {      // (levelled, the two deals have the same largest share; never let the optional one fail the call)
+                s->stream_deal_alt_off = (uint32_t)large.size(); s->stream_deal_alt_n = (uint32_t)deal.size();
+                s->stream_deal_n = (uint32_t)large.size();
+                large.insert(large.end(), deal.begin(), deal.end());
+                deal.swap(large);
+                most = std::max(most, most_large);
+            }
         }
         if ((rc = upload(s->d_deal, deal.data(), deal.size(), s->stream)) != ER_OK) return rc;
         HIP_TRY(hipStreamSynchronize(s->stream));          // (`deal` goes out of scope)
