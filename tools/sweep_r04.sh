@@ -3,7 +3,7 @@
 #   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU, fused schedule
 #   bash tools/sweep_r04.sh c4     -> C4: tracer/shader split, ring-visit and batch thresholds
 set -o pipefail
-what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13|diet|supertile|supertile2|supertile3|level|edgeauto}
+what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13|diet|supertile|supertile2|supertile3|level|edgeauto|sharesedge}
 out=gpurun_out/sweep_r04_$what
 mkdir -p $out
 line() { python3 -c "
@@ -140,4 +140,13 @@ if [ "$what" = edgeauto ]; then      # the deal that starts on 16 x 16-tile regi
   run c5_edge8 ER_STREAM_VERBOSE=1 ER_STREAM_SUPER_TILE=8 -- --config C5 --steps 12 --warmup 3; show c5_edge8
   run c5nl_auto ER_STREAM_VERBOSE=1 -- --config C5 --no-lights --steps 12 --warmup 3; show c5nl_auto
   run sim2_auto ER_STREAM_VERBOSE=1 -- --sim-world 2 --steps 20 --warmup 5; show sim2_auto
+fi
+if [ "$what" = sharesedge ]; then      # a GPU's half and quarter of the C2 frame on 8 x 8 and 16 x 16-tile regions per XCD (fixed), alternating
+  for i in 1 2; do
+    for w in 2 4; do
+      run s${w}_st8_$i ER_STREAM_VERBOSE=1 ER_STREAM_SUPER_TILE=8 -- --sim-world $w --steps 20 --warmup 5
+      run s${w}_st16_$i ER_STREAM_VERBOSE=1 ER_STREAM_SUPER_TILE=16 -- --sim-world $w --steps 20 --warmup 5
+      grep -h "XCDs finished" $out/s${w}_st16_$i.err | head -2 | sed 's/^/   /'
+    done
+  done
 fi
