@@ -116,7 +116,9 @@ static_assert((1u << ST_RQ_LOG2) >= ER_STREAM_SLOTS && (1u << ST_RQ_LOG2) >= 4u 
 #ifndef ER_STREAM_TOP_NODES
 #define ER_STREAM_TOP_NODES 900
 #endif
+#ifndef ST_MAX_TRACERS
 #define ST_MAX_TRACERS 13
+#endif
 enum { C_LIVE = 0, C_DONE, C_INIT, C_WORDS };
 #ifndef ST_IDLE_SLEEP
 #define ST_IDLE_SLEEP 16         // s_sleep argument (x 64 cycles) of a wave that found nothing to do (4 .. 48 measured: no difference)
