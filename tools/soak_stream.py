@@ -24,3 +24,20 @@ if sc is not None:
     for p in ("beauty", "normal", "tangent", "bitangent"):
         assert (w[p].view(np.uint32) == s[p].view(np.uint32)).all(), p
     print("soak 2: torture scene with lights + MIS, 48 spp x 16 bounces, stream == wavefront,", round(time.time() - t0, 1), "s")
+# soak 3 / 4: BASELINE's configurations in full -- C2 at its 256 spp, C4 at its 1 024 spp -- streaming schedule in uneven calls against the
+# wavefront schedule in one, bit for bit (planes, RNG state, sample counts), with the wall time of the streaming render
+for name, sc, spp, chunks, mb in (("C2 1920x1080 x 256 spp", scenes.soup(1_000_000, 1920, 1080, seed=12345), 256, [1, 7, 56, 192], 8),
+                                 ("C4 3840x2160 x 1024 spp", scenes.blob_instances(), 1024, [3, 61, 960], 8)):
+    if name.startswith("C4") and os.environ.get("ER_SOAK_C4", "1") == "0":
+        continue
+    t0 = time.time()
+    w = gpu_render(sc, spp, max_bounces=mb, flags=abi.FLAG_WAVEFRONT)
+    t1 = time.time()
+    s = gpu_render(sc, spp, max_bounces=mb, chunks=chunks)          # flags = 0: the library's own choice (the streaming schedule)
+    t2 = time.time()
+    for p in ("beauty", "normal", "tangent", "bitangent"):
+        assert (w[p].view(np.uint32) == s[p].view(np.uint32)).all(), p
+    assert (w["rng"] == s["rng"]).all() and (w["samples"] == s["samples"]).all() and (s["samples"] == spp + 1).mean() > 0.999          # (a sample whose light is NaN is not accumulated: the only exceptions)
+    print(f"soak: {name}: default schedule in {len(chunks)} calls == wavefront bit for bit; wall time incl. scene set-up and read-back {t2 - t1:.1f} s (wavefront {t1 - t0:.1f} s), "
+          f"{s['counters']['bounce_samples'] / 1e6:.0f} M samples", flush=True)
+    del w, s
