@@ -567,6 +567,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     } else if (s->params.flags & ER_FLAG_STREAM) {
         HIP_TRY(hipMemsetAsync(s->stream_ctl + 2, 0, 22 * sizeof(uint32_t), s->stream));      // the call's lane-occupancy counts, its end per XCD ...
         HIP_TRY(hipMemsetAsync(s->stream_ctl + 6, 0xFF, 2 * sizeof(uint32_t), s->stream));    // ... and its start (a minimum)
+        if (n > 0) s->stream_launches++;
         er_launch_stream(s->dev, s->d_dev.p, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_deal.p + s->stream_deal_off, s->stream_deal_n, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
                          s->stream_blocks, s->stream_tracers, s->stream_waves, s->stream);
     } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
@@ -658,6 +659,8 @@ int er_scene_stream_status(ErScene* s, const char* who) {
 // completed call while the lanes are under 0.85 full, down to 10 + 6 (7 + 5 of 12 waves).  The image does not depend on the split.
 static void er_stream_adapt(ErScene* s) {
     const bool verbose = getenv("ER_STREAM_VERBOSE") != nullptr;      // (read per call: a test turns it on for one render)
+    if (s->stream_adapted == s->stream_launches) return;              // (a second er_wait after the same launch: its measurements have been used)
+    s->stream_adapted = s->stream_launches;
     if (verbose && (s->params.flags & ER_FLAG_STREAM) && !s->stream_adapt) fprintf(stderr, "[er_stream] tracer lanes %.3f full at %u + %u waves (fixed split)\n", s->stream_busy, s->stream_tracers, s->stream_waves - s->stream_tracers);
     // the deal: large screen regions per XCD only while the XCDs finish together (er_stream.h, er_render_begin)
     if ((s->params.flags & ER_FLAG_STREAM) && s->stream_deal_alt_n && s->stream_xcd_spread >= 0.0) {

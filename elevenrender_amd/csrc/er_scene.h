@@ -191,6 +191,7 @@ struct ErScene {
     uint32_t stream_deal_off = 0, stream_deal_n = 0;    //   the deal in use inside d_deal (entries): the one of large super-tiles first, the default edge's after it
     uint32_t stream_deal_alt_off = 0, stream_deal_alt_n = 0;   //   the fallback deal (0 entries: none), taken when the XCDs of a call finished too far apart
     double stream_xcd_spread = 0.0;                     //   (latest - earliest XCD) / launch duration of the last completed call; < 0: not measured
+    uint64_t stream_launches = 0, stream_adapted = 0;   //   launches enqueued / the launch whose measurements er_stream_adapt has already used
     std::vector<WfState> wf;              // slot pools (see er_render_begin)
     std::vector<hipStream_t> pool_streams;   // pool 0 runs on `stream`, pool p > 0 on pool_streams[p - 1]
     std::vector<hipEvent_t> pool_events;     // [0] fork; [p] pool p has finished
