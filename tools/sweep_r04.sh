@@ -3,7 +3,7 @@
 #   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU, fused schedule
 #   bash tools/sweep_r04.sh c4     -> C4: tracer/shader split, ring-visit and batch thresholds
 set -o pipefail
-what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13|diet|supertile|supertile2|supertile3|level|edgeauto|sharesedge|feedback}
+what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13|diet|supertile|supertile2|supertile3|level|edgeauto|sharesedge}
 out=gpurun_out/sweep_r04_$what
 mkdir -p $out
 line() { python3 -c "
@@ -148,18 +148,5 @@ if [ "$what" = sharesedge ]; then      # a GPU's half and quarter of the C2 fram
       run s${w}_st16_$i ER_STREAM_VERBOSE=1 ER_STREAM_SUPER_TILE=16 -- --sim-world $w --steps 20 --warmup 5
       grep -h "XCDs finished" $out/s${w}_st16_$i.err | head -2 | sed 's/^/   /'
     done
-  done
-fi
-if [ "$what" = feedback ]; then      # the XCDs' shares of the tiles fed back from their measured durations, on / off, alternating
-  show() { grep -h "XCDs finished\|shares of" $out/$1.err | sed 's/^/   /'; }
-  for i in 1 2 3; do
-    run c2_on_$i ER_STREAM_VERBOSE=1 -- --steps 20 --warmup 5; show c2_on_$i
-    run c2_off_$i ER_STREAM_VERBOSE=1 ER_STREAM_FEEDBACK=0 -- --steps 20 --warmup 5; show c2_off_$i
-  done
-  for i in 1 2; do
-    run c4_on_$i ER_STREAM_VERBOSE=1 -- --config C4 --steps 6 --warmup 2; show c4_on_$i
-    run c4_off_$i ER_STREAM_VERBOSE=1 ER_STREAM_FEEDBACK=0 -- --config C4 --steps 6 --warmup 2; show c4_off_$i
-    run c5_on_$i ER_STREAM_VERBOSE=1 -- --config C5 --steps 12 --warmup 3; show c5_on_$i
-    run c5_off_$i ER_STREAM_VERBOSE=1 ER_STREAM_FEEDBACK=0 -- --config C5 --steps 12 --warmup 3; show c5_off_$i
   done
 fi
