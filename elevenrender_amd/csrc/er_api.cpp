@@ -264,10 +264,28 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     const bool lights_on = (p->flags & ER_FLAG_POINT_LIGHTS) != 0 && !s->point_lights.empty();
 
     // textures: one float pool + a table
+    // A texture that materials use ONLY for scalar channels -- opacity, roughness, metallic, transmission take `.x` of the fetched value
+    // (src/kernel.cpp:100-150) -- is kept on the device with its first channel alone: a one-channel fetch returns that value in .x
+    // (src/Texture.cpp:181-184), the filter's arithmetic on .x is the same, and the pool of C5 (64 x 3 noise textures of 3 channels, two
+    // of the three used for roughness and metallic) shrinks from 151 MB to 84 MB of the caches it shares with the tree.
+    std::vector<uint8_t> vec_use(s->textures.size(), 0), scal_use(s->textures.size(), 0);
+    auto mark = [&](std::vector<uint8_t>& v, int32_t id) { if (id >= 0 && (size_t)id < v.size()) v[(size_t)id] = 1; };
+    for (const ErMaterial& m : s->materials) {
+        mark(vec_use, m.albedo_tex); mark(vec_use, m.emission_tex); mark(vec_use, m.normal_tex);
+        mark(scal_use, m.opacity_tex); mark(scal_use, m.roughness_tex); mark(scal_use, m.metallic_tex); mark(scal_use, m.transmission_tex);
+    }
+    const char* compact_knob = getenv("ER_TEX_COMPACT");      // (A/B and test knob: 0 = every texture as it came)
+    const bool compact = !(compact_knob && atoi(compact_knob) == 0);
     std::vector<DevTex> table(s->textures.size());
     std::vector<float> pool;
     for (size_t i = 0; i < s->textures.size(); i++) {
         const HostTex& t = s->textures[i];
+        if (compact && t.channels > 1 && scal_use[i] && !vec_use[i]) {
+            table[i] = DevTex{t.width, t.height, 1, t.filter, (uint32_t)pool.size()};
+            const size_t n = (size_t)t.width * (size_t)t.height;
+            for (size_t k = 0; k < n; k++) pool.push_back(t.data[k * (size_t)t.channels]);
+            continue;
+        }
         table[i] = DevTex{t.width, t.height, t.channels, t.filter, (uint32_t)pool.size()};
         pool.insert(pool.end(), t.data.begin(), t.data.end());
     }

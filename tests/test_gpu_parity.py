@@ -575,3 +575,25 @@ def test_deal_falls_back_when_the_xcds_finish_apart_and_the_image_does_not_chang
     lines = [l for l in err.splitlines() if l.startswith("[er_stream] XCDs finished")]
     assert lines and "super-tiles of 16 -> the default deal" in lines[0], err
     assert not any("super-tiles of 16" in l for l in lines[1:]), lines
+
+
+def test_scalar_only_textures_kept_with_one_channel_do_not_change_the_image(oracle_mod, monkeypatch):
+    """A texture that materials use for scalar channels only -- opacity, roughness, metallic, transmission take `.x` of the fetched value
+    (src/kernel.cpp:100-150) -- is kept on the device with its first channel alone (csrc/er_api.cpp; C5's texture pool: 151 -> 84 MB).
+    The image must be that of the textures as they came (ER_TEX_COMPACT=0) and the oracle's, bit for bit, on a scene that has all three
+    kinds: textures used as colours only, as scalars only (3- and 2-channel, filtered and not), and as both (kept whole)."""
+    sc = scenes.torture(3000, 96, 64, seed=5, n_materials=6, tex_size=16, hdri_size=(64, 32), n_lights=0)
+    r = scenes.Rand(91, 2)
+    sc.textures.append((abi._f32(r.u01(8, 8, 2)), 8, 8, 2, 1))          # a 2-channel bilinear texture, used as opacity below
+    sc.materials[0].opacity_tex = len(sc.textures) - 1
+    sc.materials[1].roughness_tex = sc.materials[1].albedo_tex             # one texture as a colour AND as a scalar: stays whole
+    sc.materials[2].transmission_tex = sc.materials[3].metallic_tex        # a scalar-only texture shared by two materials
+    sc._desc = None
+    compact = gpu_render(sc, 5, max_bounces=8, flags=abi.FLAG_STREAM)
+    monkeypatch.setenv("ER_TEX_COMPACT", "0")
+    as_is = gpu_render(sc, 5, max_bounces=8, flags=abi.FLAG_STREAM)
+    monkeypatch.delenv("ER_TEX_COMPACT")
+    for p in ("beauty", "normal", "tangent", "bitangent"):
+        assert (compact[p].view(np.uint32) == as_is[p].view(np.uint32)).all(), p
+    assert (compact["rng"] == as_is["rng"]).all()
+    compare(compact, oracle_render(oracle_mod, sc, 5, max_bounces=8), what="scalar-only textures with one channel")

@@ -3,7 +3,7 @@
 #   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU, fused schedule
 #   bash tools/sweep_r04.sh c4     -> C4: tracer/shader split, ring-visit and batch thresholds
 set -o pipefail
-what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13|diet|supertile|supertile2|supertile3|level|edgeauto|sharesedge}
+what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13|diet|supertile|supertile2|supertile3|level|edgeauto|sharesedge|texcompact}
 out=gpurun_out/sweep_r04_$what
 mkdir -p $out
 line() { python3 -c "
@@ -148,5 +148,15 @@ if [ "$what" = sharesedge ]; then      # a GPU's half and quarter of the C2 fram
       run s${w}_st16_$i ER_STREAM_VERBOSE=1 ER_STREAM_SUPER_TILE=16 -- --sim-world $w --steps 20 --warmup 5
       grep -h "XCDs finished" $out/s${w}_st16_$i.err | head -2 | sed 's/^/   /'
     done
+  done
+fi
+if [ "$what" = texcompact ]; then      # scalar-only textures kept with one channel (default) against every texture as it came, alternating
+  for i in 1 2 3; do
+    run c5_compact_$i X=1 -- --config C5 --steps 12 --warmup 3
+    run c5_as_is_$i ER_TEX_COMPACT=0 -- --config C5 --steps 12 --warmup 3
+  done
+  for i in 1 2; do
+    run c5nl_compact_$i X=1 -- --config C5 --no-lights --steps 12 --warmup 3
+    run c5nl_as_is_$i ER_TEX_COMPACT=0 -- --config C5 --no-lights --steps 12 --warmup 3
   done
 fi
