@@ -268,11 +268,15 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     // (src/kernel.cpp:100-150) -- is kept on the device with its first channel alone: a one-channel fetch returns that value in .x
     // (src/Texture.cpp:181-184), the filter's arithmetic on .x is the same, and the pool of C5 (64 x 3 noise textures of 3 channels, two
     // of the three used for roughness and metallic) shrinks from 151 MB to 84 MB of the caches it shares with the tree.
-    std::vector<uint8_t> vec_use(s->textures.size(), 0), scal_use(s->textures.size(), 0);
+    // And where such a texture is read UNFILTERED and only as roughness or metallic, what it holds is the value to the power 2.2 that
+    // generateHitData takes of every fetch (src/kernel.cpp:152-153), computed here with the device's own er_pow (er_math.h: one
+    // implementation, the same bits -- as for the constants of DevScene::mat_pre); DevTex::filter = 2 marks it (fetched like filter 0).
+    std::vector<uint8_t> vec_use(s->textures.size(), 0), scal_use(s->textures.size(), 0), plain_use(s->textures.size(), 0);
     auto mark = [&](std::vector<uint8_t>& v, int32_t id) { if (id >= 0 && (size_t)id < v.size()) v[(size_t)id] = 1; };
     for (const ErMaterial& m : s->materials) {
         mark(vec_use, m.albedo_tex); mark(vec_use, m.emission_tex); mark(vec_use, m.normal_tex);
         mark(scal_use, m.opacity_tex); mark(scal_use, m.roughness_tex); mark(scal_use, m.metallic_tex); mark(scal_use, m.transmission_tex);
+        mark(plain_use, m.opacity_tex); mark(plain_use, m.transmission_tex);      // (scalar channels that are NOT raised to a power)
     }
     const char* compact_knob = getenv("ER_TEX_COMPACT");      // (A/B and test knob: 0 = every texture as it came)
     const bool compact = !(compact_knob && atoi(compact_knob) == 0);
@@ -280,13 +284,19 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     std::vector<float> pool;
     for (size_t i = 0; i < s->textures.size(); i++) {
         const HostTex& t = s->textures[i];
-        if (compact && t.channels > 1 && scal_use[i] && !vec_use[i]) {
-            table[i] = DevTex{t.width, t.height, 1, t.filter, (uint32_t)pool.size()};
-            const size_t n = (size_t)t.width * (size_t)t.height;
-            for (size_t k = 0; k < n; k++) pool.push_back(t.data[k * (size_t)t.channels]);
-            continue;
+        if (compact && t.channels >= 1 && scal_use[i] && !vec_use[i]) {
+            const bool powered = t.filter != 1 && !plain_use[i] && !getenv("ER_MAT_PRE_ON_DEVICE");
+            if (t.channels > 1 || powered) {
+                table[i] = DevTex{t.width, t.height, 1, powered ? 2 : (t.filter == 1 ? 1 : 0), (uint32_t)pool.size()};
+                const size_t n = (size_t)t.width * (size_t)t.height;
+                for (size_t k = 0; k < n; k++) {
+                    const float v = t.data[k * (size_t)t.channels];
+                    pool.push_back(powered ? ermath::er_pow(v, 2.2f) : v);
+                }
+                continue;
+            }
         }
-        table[i] = DevTex{t.width, t.height, t.channels, t.filter, (uint32_t)pool.size()};
+        table[i] = DevTex{t.width, t.height, t.channels, t.filter == 1 ? 1 : 0, (uint32_t)pool.size()};      // (anything but BILINEAR fetches unfiltered, src/Texture.cpp:229-236; 2 is the library's own mark)
         pool.insert(pool.end(), t.data.begin(), t.data.end());
     }
     DevTex hd{s->hdri_tex.width, s->hdri_tex.height, s->hdri_tex.channels, s->hdri_tex.filter, (uint32_t)pool.size()};

@@ -620,8 +620,11 @@ ERD void generate_hit_data(const DevScene& S, const ErMaterial& mat, const HitFu
     // roughness and metallic to the power 2.2 (src/kernel.cpp:152-153): of a constant channel once per material on the host, of a
     // textured one here
     const float4 pre = S.mat_pre[hit.material];
-    hd.roughness = mat.roughness_tex < 0 ? pre.x : ermath::er_pow(hd.roughness, 2.2f);
-    hd.metallic = mat.metallic_tex < 0 ? pre.y : ermath::er_pow(hd.metallic, 2.2f);
+    // (... and of a texture the host already holds to that power: DevTex::filter == 2, er_api.cpp)
+    if (mat.roughness_tex < 0) hd.roughness = pre.x;
+    else if (S.textures[mat.roughness_tex].filter != 2) hd.roughness = ermath::er_pow(hd.roughness, 2.2f);
+    if (mat.metallic_tex < 0) hd.metallic = pre.y;
+    else if (S.textures[mat.metallic_tex].filter != 2) hd.metallic = ermath::er_pow(hd.metallic, 2.2f);
     hd.gtr1_log = pre.w != 0.0f ? pre.z : __builtin_nanf("");
     hd.clearcoatGloss = mat.clearcoat_gloss;
     hd.clearcoat = mat.clearcoat;

@@ -587,8 +587,13 @@ def test_scalar_only_textures_kept_with_one_channel_do_not_change_the_image(orac
     sc.textures.append((abi._f32(r.u01(8, 8, 2)), 8, 8, 2, 1))          # a 2-channel bilinear texture, used as opacity below
     sc.materials[0].opacity_tex = len(sc.textures) - 1
     sc.materials[1].roughness_tex = sc.materials[1].albedo_tex             # one texture as a colour AND as a scalar: stays whole
-    sc.materials[2].transmission_tex = sc.materials[3].metallic_tex        # a scalar-only texture shared by two materials
+    sc.materials[2].transmission_tex = sc.materials[3].metallic_tex        # a scalar-only texture shared by two materials: as metallic AND as transmission
+    d, w, h, ch, _ = sc.textures[sc.materials[4].roughness_tex]
+    sc.textures[sc.materials[4].roughness_tex] = (d, w, h, ch, 1)           # a BILINEAR roughness texture
     sc._desc = None
+    # (the unfiltered textures that are read only as roughness or metallic are also held to the power 2.2 that generateHitData takes of
+    # every fetch, src/kernel.cpp:152-153 -- not the bilinear one, whose power is of the FILTERED value, nor the one that is also a
+    # transmission, which takes none; ER_TEX_COMPACT=0 switches both off)
     compact = gpu_render(sc, 5, max_bounces=8, flags=abi.FLAG_STREAM)
     monkeypatch.setenv("ER_TEX_COMPACT", "0")
     as_is = gpu_render(sc, 5, max_bounces=8, flags=abi.FLAG_STREAM)
