@@ -243,7 +243,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         memcpy(geom.data() + n8_pieces, isect.data(), (n + 1) * sizeof(ErTriIsect));
         if (geom.size() >= (1ull << 30)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: geometry exceeds the 16 GB addressable by the wide traversal");
         if ((rc = upload(s->d_nodes8, geom.data(), geom.size(), s->stream)) != ER_OK) return rc;
-        if ((rc = upload(s->d_attr, attr.data(), n * 7, s->stream)) != ER_OK) return rc;
+        if ((rc = upload(s->d_attr, attr.data(), n * ER_ATTR_PIECES, s->stream)) != ER_OK) return rc;
         bvh2_nodes = (uint32_t)bvh.nodes.size(); wide_nodes = (uint32_t)bvh.nodes8.size(); wide_depth = bvh.max_depth8; leaf_count = bvh.leaf_count;
         for (int a = 0; a < 3; a++) { bvh_lo[a] = bvh.lo[a]; bvh_hi[a] = bvh.hi[a]; }
         lift_bound = bvh.lift_bound;

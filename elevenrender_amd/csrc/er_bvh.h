@@ -37,14 +37,17 @@ struct ErTriIsect {         // 48 bytes: what a triangle test reads
 };
 static_assert(sizeof(ErTriIsect) == 48, "isect record must be 48 bytes");
 
-struct ErTriAttr {          // 112 bytes: read for candidates (normals) and for the shaded hit (all)
+#ifndef ER_ATTR_PIECES
+#define ER_ATTR_PIECES 7    // 16-byte pieces per attribute record: 7 = 112 bytes packed, 8 = one record per 128-byte line
+#endif
+struct ErTriAttr {          // 112 bytes (+ padding to ER_ATTR_PIECES x 16): read for candidates (normals) and for the shaded hit (all)
     float n[3][3];          // 36
     float t[3][3];          // 36
     float uv[3][2];         // 24
     int32_t material;       // 4
-    float pad[3];           // -> 112
+    float pad[3 + 4 * (ER_ATTR_PIECES - 7)];           // -> 112 / 128
 };
-static_assert(sizeof(ErTriAttr) == 112, "attr record must be 112 bytes");
+static_assert(sizeof(ErTriAttr) == 16 * ER_ATTR_PIECES, "attr record must be ER_ATTR_PIECES pieces");
 
 // 8-wide compressed node (layout after Ylitie, Karras, Laine 2017, "Efficient incoherent ray traversal on
 // GPUs through compressed wide BVHs"): child boxes are 8-bit offsets from `p` in units of 2^e per axis,

@@ -260,7 +260,7 @@ ERD void load_verts(const DevScene& S, uint32_t slot, F3& v0, F3& v1, F3& v2, fl
     v0 = f3(a.x, a.y, a.z); v1 = f3(b.x, b.y, b.z); v2 = f3(c.x, c.y, c.z);
 }
 ERD void load_normals(const DevScene& S, uint32_t slot, F3& n0, F3& n1, F3& n2) {
-    const float4* p = S.tri_attr + (size_t)slot * 7;
+    const float4* p = S.tri_attr + (size_t)slot * ER_ATTR_PIECES;
     float4 a = p[0], b = p[1], c = p[2];
     n0 = f3(a.x, a.y, a.z); n1 = f3(a.w, b.x, b.y); n2 = f3(b.z, b.w, c.x);
 }
@@ -280,7 +280,7 @@ ERD void full_hit(const DevScene& S, uint32_t slot, const Ray& ray, HitFull& h) 
     load_verts(S, slot, v0, v1, v2, a, b, c);
     float u = 0, v = 0, t = 0;
     tri_mt(v0, v1, v2, ray, u, v, t);
-    const float4* p = S.tri_attr + (size_t)slot * 7;
+    const float4* p = S.tri_attr + (size_t)slot * ER_ATTR_PIECES;
     float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4 = p[4], q5 = p[5], q6 = p[6];
     F3 n0 = f3(q0.x, q0.y, q0.z), n1 = f3(q0.w, q1.x, q1.y), n2 = f3(q1.z, q1.w, q2.x);
     F3 t0 = f3(q2.y, q2.z, q2.w), t1 = f3(q3.x, q3.y, q3.z), t2 = f3(q3.w, q4.x, q4.y);

@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void k_records(const uint32_t* __restrict__ ne
         for (int a = 0; a < 3; a++) { t.n[j][a] = nrm[(size_t)id * 9 + 3 * j + a]; t.t[j][a] = tan[(size_t)id * 9 + 3 * j + a]; }
     for (int j = 0; j < 3; j++) { t.uv[j][0] = uv[(size_t)id * 6 + 2 * j]; t.uv[j][1] = uv[(size_t)id * 6 + 2 * j + 1]; }
     t.material = mat[id];
-    t.pad[0] = t.pad[1] = t.pad[2] = 0;
+    for (unsigned j = 0; j < sizeof(t.pad) / sizeof(t.pad[0]); j++) t.pad[j] = 0;
     attr[k] = t;
     slot_to_tri[k] = id;
 }
@@ -663,7 +663,7 @@ int er_gpu_build_device(const ErGpuSceneArrays& a, uint32_t n, int device, ErGpu
     const size_t geom_f4 = n8_pieces + ((size_t)n + 1) * 3;
     Dev<float4> d_geom, d_attr;
     GB_OK(hipMalloc(&d_geom.p, geom_f4 * 16));
-    GB_OK(hipMalloc(&d_attr.p, (size_t)n * 7 * 16));
+    GB_OK(hipMalloc(&d_attr.p, (size_t)n * ER_ATTR_PIECES * 16));
     GB_OK(hipMemsetAsync(d_geom.p, 0, n8_pieces * 16, st));
     GB_OK(hipMemcpy2DAsync(d_geom.p, (size_t)ER_NODE8_PIECES * 16, d_n8.p, sizeof(ErNode8), sizeof(ErNode8), nodes8_count, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_records, dim3((n + 256) / 256), dim3(256), 0, st, d_new_order.p, B.d_ids2.p, n, B.d_v.p, B.d_n.p, d_tan.p, d_uv.p, d_sign.p,
@@ -681,7 +681,7 @@ int er_gpu_build_device(const ErGpuSceneArrays& a, uint32_t n, int device, ErGpu
     out->n8_pieces = n8_pieces;
     out->geom_f4 = geom_f4;
     out->nodes_f4 = (size_t)n_inner * 4;
-    out->attr_f4 = (size_t)n * 7;
+    out->attr_f4 = (size_t)n * ER_ATTR_PIECES;
     out->nodes = (float4*)B.d_nodes.take();
     out->geom = d_geom.take();
     out->attr = d_attr.take();
