@@ -299,6 +299,40 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         table[i] = DevTex{t.width, t.height, t.channels, t.filter == 1 ? 1 : 0, (uint32_t)pool.size()};      // (anything but BILINEAR fetches unfiltered, src/Texture.cpp:229-236; 2 is the library's own mark)
         pool.insert(pool.end(), t.data.begin(), t.data.end());
     }
+    // A material whose albedo, roughness and metallic textures have one size and one filter gets them texel by texel in one record of
+    // five floats (DevFused, er_device.h): one fetch, one cache line and one coordinate computation per hit instead of three.  The
+    // texel values are what Texture::getValueFromCoordinates returns for each (src/Texture.cpp:172-200); unfiltered, roughness and
+    // metallic are stored to the power 2.2 as above.  The textures themselves stay where they are for every other use.
+    std::vector<DevFused> fused(std::max<size_t>(1, s->materials.size()), DevFused{0, 0, 0, 0});
+    const char* fuse_knob = getenv("ER_TEX_FUSE");      // (A/B knob; ER_TEX_COMPACT=0 = "every texture as it came" switches this off as well)
+    if (compact && !(fuse_knob && atoi(fuse_knob) == 0)) {
+        for (size_t m = 0; m < s->materials.size(); m++) {
+            const ErMaterial& M = s->materials[m];
+            const int32_t ids[3] = {M.albedo_tex, M.roughness_tex, M.metallic_tex};
+            bool ok = true;
+            for (int32_t id : ids) ok = ok && id >= 0 && (size_t)id < s->textures.size();
+            if (!ok) continue;
+            const HostTex &A = s->textures[(size_t)ids[0]], &R = s->textures[(size_t)ids[1]], &K = s->textures[(size_t)ids[2]];
+            if (A.width != R.width || A.width != K.width || A.height != R.height || A.height != K.height) continue;
+            if ((A.filter == 1) != (R.filter == 1) || (A.filter == 1) != (K.filter == 1)) continue;
+            if (A.channels < 1 || R.channels < 1 || K.channels < 1) continue;
+            const bool bilinear = A.filter == 1, powered = !bilinear && !getenv("ER_MAT_PRE_ON_DEVICE");
+            const size_t n = (size_t)A.width * (size_t)A.height;
+            if (pool.size() + 5 * n >= (1ull << 32)) continue;
+            fused[m] = DevFused{A.width, A.height, bilinear ? 1 : (powered ? 2 : 0), (uint32_t)pool.size()};
+            for (size_t k = 0; k < n; k++) {
+                const float* a = A.data.data() + k * (size_t)A.channels;
+                const float r = R.data[k * (size_t)R.channels], mt = K.data[k * (size_t)K.channels];
+                // (one channel: the value three times; two: x, y, 0; three or more: the first three -- src/Texture.cpp:181-197)
+                pool.push_back(a[0]);
+                pool.push_back(A.channels == 1 ? a[0] : a[1]);
+                pool.push_back(A.channels == 1 ? a[0] : (A.channels == 2 ? 0.0f : a[2]));
+                pool.push_back(powered ? ermath::er_pow(r, 2.2f) : r);
+                pool.push_back(powered ? ermath::er_pow(mt, 2.2f) : mt);
+            }
+        }
+    }
+    if ((rc = upload(s->d_mat_fused, fused.data(), fused.size(), s->stream)) != ER_OK) return rc;
     DevTex hd{s->hdri_tex.width, s->hdri_tex.height, s->hdri_tex.channels, s->hdri_tex.filter, (uint32_t)pool.size()};
     pool.insert(pool.end(), s->hdri_tex.data.begin(), s->hdri_tex.data.end());
     if (pool.size() >= (1ull << 32)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: texture pool exceeds 2^32 floats");
@@ -515,6 +549,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     D.mat_pre = s->d_mat_pre.p;
     D.textures = s->d_textures.p;
     D.tex_pool = s->d_tex_pool.p;
+    D.mat_fused = s->d_mat_fused.p;
     D.hdri_tex = hd;
     D.hdri_cdf = s->d_cdf.p;
     D.hdri_guide = s->d_guide.p;

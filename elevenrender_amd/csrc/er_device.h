@@ -34,6 +34,15 @@ struct DevTex {
     uint32_t offset;   // into tex_pool (floats)
 };
 
+// A material whose albedo, roughness and metallic textures have one size and one filter: the three texel by texel, five floats per texel
+// (albedo r g b as Texture::getValueFromCoordinates returns it, roughness, metallic = the first channels), made by er_api.cpp.  One fetch
+// (one cache line, one coordinate computation) instead of three per hit.  filter: 1 bilinear, 0 unfiltered, 2 unfiltered with roughness
+// and metallic already to the power 2.2 (src/kernel.cpp:152-153); width = 0: the material is not fused.
+struct DevFused {
+    int32_t width, height, filter;
+    uint32_t offset;   // into tex_pool (floats)
+};
+
 struct DevCounters {
     unsigned long long paths, bounce_samples, rays, node_visits, tri_tests, shaded_hits, texel_fetches, hdri_samples;
     unsigned long long trace_wave_steps, trace_busy_lanes, trace_node_lanes, trace_tri_lanes;
@@ -58,6 +67,7 @@ struct DevScene {
     // evaluation (src/Disney.cpp:40-46); w = 1 if z is valid (a < 1)
     const float4* mat_pre;
     const DevTex* textures;
+    const DevFused* mat_fused;  // per material (above)
     const float* tex_pool;
     DevTex hdri_tex;
     const float* hdri_cdf;
@@ -428,6 +438,32 @@ ERD F3 tex_bilinear(const DevScene& S, const DevTex& t, float u, float v) {
 ERD F3 tex_filtered(const DevScene& S, const DevTex& t, float u, float v) {
     return t.filter == 1 ? tex_bilinear(S, t, u, v) : tex_uv(S, t, u, v);
 }
+// the fused texel of a material (DevFused): the statements of tex_coords / tex_bilinear on all five channels at once
+ERD void fused_coords(const DevScene& S, const DevFused& t, int x, int y, F3& alb, F3& rm) {
+    x = wrap_abs(x, t.width, S.tex_pow2 != 0u);
+    y = wrap_abs(y, t.height, S.tex_pow2 != 0u);
+    const float* d = S.tex_pool + t.offset + 5u * (uint32_t)(y * t.width + x);
+    alb = f3(d[0], d[1], d[2]);
+    rm = f3(d[3], d[4], 0.0f);
+}
+ERD void fused_fetch(const DevScene& S, const DevFused& t, float u, float v, F3& alb, F3& rm) {
+    if (t.filter == 1) {
+        float x = u * t.width, y = v * t.height;
+        float t1x = __builtin_floorf(x), t1y = __builtin_floorf(y);
+        float t2x = t1x + 1, t2y = t1y + 1;
+        float a = (x - t1x) / (t2x - t1x);
+        float b = (y - t1y) / (t2y - t1y);
+        F3 a1, a2, a3, a4, r1, r2, r3, r4;
+        fused_coords(S, t, ermath::f2i(t1x), ermath::f2i(t1y), a1, r1);
+        fused_coords(S, t, ermath::f2i(t2x), ermath::f2i(t1y), a2, r2);
+        fused_coords(S, t, ermath::f2i(t1x), ermath::f2i(t2y), a3, r3);
+        fused_coords(S, t, ermath::f2i(t2x), ermath::f2i(t2y), a4, r4);
+        alb = lerpv(lerpv(a1, a2, a), lerpv(a3, a4, a), b);
+        rm = lerpv(lerpv(r1, r2, a), lerpv(r3, r4, a), b);
+    } else {
+        fused_coords(S, t, ermath::f2i(u * t.width), ermath::f2i(v * t.height), alb, rm);
+    }
+}
 ERD void spherical_mapping(F3 point, float& u, float& v) {   // src/Texture.cpp:239-251 (origin 0, radius 1)
     F3 p = (point - f3s(0)) / 1.0f;
     float theta = ermath::er_acos(-p.y);
@@ -597,15 +633,21 @@ ERD F3 DisneyEval(const HitData& hd, F3 V, F3 N, F3 L) {   // src/Disney.cpp:160
 // ---- generateHitData, src/kernel.cpp:76-172 ----------------------------------------
 template <bool COUNT>
 ERD void generate_hit_data(const DevScene& S, const ErMaterial& mat, const HitFull& hit, HitData& hd, unsigned& texels) {
-    if (mat.albedo_tex < 0) hd.albedo = f3(mat.albedo.x, mat.albedo.y, mat.albedo.z);
+    const DevFused fu = S.mat_fused[hit.material];
+    const bool fused = fu.width > 0;      // albedo, roughness and metallic of this material come from one fused texel
+    F3 fu_rm = f3s(0);
+    if (fused) { fused_fetch(S, fu, hit.tu, hit.tv, hd.albedo, fu_rm); if (COUNT) texels += 3; }
+    else if (mat.albedo_tex < 0) hd.albedo = f3(mat.albedo.x, mat.albedo.y, mat.albedo.z);
     else { hd.albedo = tex_filtered(S, S.textures[mat.albedo_tex], hit.tu, hit.tv); if (COUNT) texels++; }
     if (mat.opacity_tex < 0) hd.opacity = mat.opacity;
     else { hd.opacity = tex_filtered(S, S.textures[mat.opacity_tex], hit.tu, hit.tv).x; if (COUNT) texels++; }
     if (mat.emission_tex < 0) hd.emission = f3(mat.emission.x, mat.emission.y, mat.emission.z);
     else { hd.emission = tex_filtered(S, S.textures[mat.emission_tex], hit.tu, hit.tv); if (COUNT) texels++; }
-    if (mat.roughness_tex < 0) hd.roughness = mat.roughness;
+    if (fused) hd.roughness = fu_rm.x;
+    else if (mat.roughness_tex < 0) hd.roughness = mat.roughness;
     else { hd.roughness = tex_filtered(S, S.textures[mat.roughness_tex], hit.tu, hit.tv).x; if (COUNT) texels++; }
-    if (mat.metallic_tex < 0) hd.metallic = mat.metallic;
+    if (fused) hd.metallic = fu_rm.y;
+    else if (mat.metallic_tex < 0) hd.metallic = mat.metallic;
     else { hd.metallic = tex_filtered(S, S.textures[mat.metallic_tex], hit.tu, hit.tv).x; if (COUNT) texels++; }
     if (mat.transmission_tex < 0) hd.transmission = mat.transmission;
     else { hd.transmission = tex_filtered(S, S.textures[mat.transmission_tex], hit.tu, hit.tv).x; if (COUNT) texels++; }
@@ -621,10 +663,14 @@ ERD void generate_hit_data(const DevScene& S, const ErMaterial& mat, const HitFu
     // textured one here
     const float4 pre = S.mat_pre[hit.material];
     // (... and of a texture the host already holds to that power: DevTex::filter == 2, er_api.cpp)
-    if (mat.roughness_tex < 0) hd.roughness = pre.x;
-    else if (S.textures[mat.roughness_tex].filter != 2) hd.roughness = ermath::er_pow(hd.roughness, 2.2f);
-    if (mat.metallic_tex < 0) hd.metallic = pre.y;
-    else if (S.textures[mat.metallic_tex].filter != 2) hd.metallic = ermath::er_pow(hd.metallic, 2.2f);
+    if (fused) {
+        if (fu.filter != 2) { hd.roughness = ermath::er_pow(hd.roughness, 2.2f); hd.metallic = ermath::er_pow(hd.metallic, 2.2f); }
+    } else {
+        if (mat.roughness_tex < 0) hd.roughness = pre.x;
+        else if (S.textures[mat.roughness_tex].filter != 2) hd.roughness = ermath::er_pow(hd.roughness, 2.2f);
+        if (mat.metallic_tex < 0) hd.metallic = pre.y;
+        else if (S.textures[mat.metallic_tex].filter != 2) hd.metallic = ermath::er_pow(hd.metallic, 2.2f);
+    }
     hd.gtr1_log = pre.w != 0.0f ? pre.z : __builtin_nanf("");
     hd.clearcoatGloss = mat.clearcoat_gloss;
     hd.clearcoat = mat.clearcoat;

@@ -177,6 +177,7 @@ struct ErScene {
     DevBuf<float> d_tex_pool, d_cdf;
     DevBuf<uint32_t> d_samples, d_rng, d_owned;
     DevBuf<DevCounters> d_counters;
+    DevBuf<DevFused> d_mat_fused;   // per material: its fused albedo / roughness / metallic texels in d_tex_pool, or width 0
     DevBuf<DevScene> d_dev;      // device copy of `dev`: the streaming kernel reads the scene descriptor through a pointer
     DevBuf<float4> d_wf4;        // 11 float4 arrays of the wavefront state, back to back
     DevBuf<uint32_t> d_wf1;      // hit, left, occluded, 4 queues, counts
@@ -218,7 +219,7 @@ struct ErScene {
     void release_device() {
         d_nodes.release(); d_nodes8.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_plane.release(); d_materials.release();
         d_textures.release(); d_tex_pool.release(); d_lights.release(); d_cdf.release(); d_samples.release(); d_rng.release();
-        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_deal.release(); d_ray_log.release();
+        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_deal.release(); d_ray_log.release(); d_mat_fused.release();
         for (auto& kv : d_rank_tiles) kv.second.release();
         d_rank_tiles.clear();
         for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);

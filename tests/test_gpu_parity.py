@@ -589,8 +589,13 @@ def test_scalar_only_textures_kept_with_one_channel_do_not_change_the_image(orac
     sc.materials[1].roughness_tex = sc.materials[1].albedo_tex             # one texture as a colour AND as a scalar: stays whole
     sc.materials[2].transmission_tex = sc.materials[3].metallic_tex        # a scalar-only texture shared by two materials: as metallic AND as transmission
     d, w, h, ch, _ = sc.textures[sc.materials[4].roughness_tex]
-    sc.textures[sc.materials[4].roughness_tex] = (d, w, h, ch, 1)           # a BILINEAR roughness texture
+    sc.textures[sc.materials[4].roughness_tex] = (d, w, h, ch, 1)           # a BILINEAR roughness texture beside an unfiltered albedo: material 4 is not fused
+    for tid in (sc.materials[5].albedo_tex, sc.materials[5].roughness_tex, sc.materials[5].metallic_tex):
+        d, w, h, ch, _ = sc.textures[tid]
+        sc.textures[tid] = (d, w, h, ch, 1)                                 # material 5: all three BILINEAR -> fused, filtered on five channels at once
     sc._desc = None
+    # (materials whose albedo / roughness / metallic textures share size and filter are fetched from ONE fused texel record, DevFused in
+    # csrc/er_device.h: here materials 0, 2, 3 unfiltered, 1 with one texture in two roles, 5 bilinear; ER_TEX_COMPACT=0 switches it off too)
     # (the unfiltered textures that are read only as roughness or metallic are also held to the power 2.2 that generateHitData takes of
     # every fetch, src/kernel.cpp:152-153 -- not the bilinear one, whose power is of the FILTERED value, nor the one that is also a
     # transmission, which takes none; ER_TEX_COMPACT=0 switches both off)

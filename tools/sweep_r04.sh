@@ -154,9 +154,11 @@ if [ "$what" = texcompact ]; then      # scalar-only textures kept with one chan
   for i in 1 2 3; do
     run c5_compact_$i X=1 -- --config C5 --steps 12 --warmup 3
     run c5_as_is_$i ER_TEX_COMPACT=0 -- --config C5 --steps 12 --warmup 3
+    run c5_unfused_$i ER_TEX_FUSE=0 -- --config C5 --steps 12 --warmup 3
   done
   for i in 1 2; do
     run c5nl_compact_$i X=1 -- --config C5 --no-lights --steps 12 --warmup 3
     run c5nl_as_is_$i ER_TEX_COMPACT=0 -- --config C5 --no-lights --steps 12 --warmup 3
+    run c5nl_unfused_$i ER_TEX_FUSE=0 -- --config C5 --no-lights --steps 12 --warmup 3
   done
 fi
