@@ -402,7 +402,10 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         // 1 489 at 13 + 3), point lights (C5: 1 350 vs 1 234), or a scene beyond the Infinity Cache (C4, 10 M triangles: 1 562 vs 1 483)
         // (profiles/r04_sweep_split_after_shader_diet.log).  That is the split to begin with; after every completed call it follows how
         // full the tracer lanes were (er_stream_adapt: a scene of another kind that starves 13 tracers gets 12 after its first call).
-        s->stream_tracers = (lights_on || !s->textures.empty() || s->tri_count > 4000000u) ? 12 : 13;
+        // (textured materials started at 12 + 4 until their textures were fused / pre-powered / one-channel, er_render_begin above: C5 without
+        // lights now 1 712 vs 1 640 at 12 + 4; a textured scene whose shading step is still too long for 13 tracers reads < 0.85 full lanes
+        // after its first call and gets 12)
+        s->stream_tracers = (lights_on || s->tri_count > 4000000u) ? 12 : 13;
         // A workgroup that owns hardly more pixels than it has slots (an eighth of a 1080p frame: 1 012 pixels per CU) cannot fill 12 tracer
         // waves -- a pixel's samples are one RNG stream, so pixels in flight are all the parallelism there is -- and runs faster as 9 tracer +
         // 3 shader waves of 168 registers (the shading step then spills 34 registers instead of 111 and three shader waves serve what four
@@ -416,7 +419,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             // (nor in the instrumented kernel of ER_FLAG_COUNTERS, whose slower tracer loop shifts the balance)
             s->stream_adapt = px_per_cu >= 4u * ER_STREAM_SLOTS && !(p->flags & ER_FLAG_COUNTERS);
         }
-        if (const char* e = getenv("ER_STREAM_WAVES")) { s->stream_waves = atoi(e) == 12 ? 12 : 16; s->stream_tracers = s->stream_waves == 12 ? 9u : ((lights_on || !s->textures.empty() || s->tri_count > 4000000u) ? 12u : 13u); }   // A/B knob
+        if (const char* e = getenv("ER_STREAM_WAVES")) { s->stream_waves = atoi(e) == 12 ? 12 : 16; s->stream_tracers = s->stream_waves == 12 ? 9u : ((lights_on || s->tri_count > 4000000u) ? 12u : 13u); }   // A/B knob
         if (const char* e = getenv("ER_STREAM_TRACERS")) { s->stream_tracers = (uint32_t)std::min(13, std::max(1, atoi(e))); s->stream_adapt = false; }   // tuning knob: fixed split
         if (const char* e = getenv("ER_STREAM_ADAPT")) s->stream_adapt = atoi(e) != 0;
         const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
