@@ -332,6 +332,8 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             }
         }
     }
+    s->fused_any = false;
+    for (const DevFused& f : fused) s->fused_any = s->fused_any || f.width > 0;
     if ((rc = upload(s->d_mat_fused, fused.data(), fused.size(), s->stream)) != ER_OK) return rc;
     DevTex hd{s->hdri_tex.width, s->hdri_tex.height, s->hdri_tex.channels, s->hdri_tex.filter, (uint32_t)pool.size()};
     pool.insert(pool.end(), s->hdri_tex.data.begin(), s->hdri_tex.data.end());
@@ -553,6 +555,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     D.textures = s->d_textures.p;
     D.tex_pool = s->d_tex_pool.p;
     D.mat_fused = s->d_mat_fused.p;
+    D.fused_any = s->fused_any ? 1u : 0u;
     D.hdri_tex = hd;
     D.hdri_cdf = s->d_cdf.p;
     D.hdri_guide = s->d_guide.p;

@@ -68,6 +68,7 @@ struct DevScene {
     const float4* mat_pre;
     const DevTex* textures;
     const DevFused* mat_fused;  // per material (above)
+    uint32_t fused_any;         // 1 if any material is fused
     const float* tex_pool;
     DevTex hdri_tex;
     const float* hdri_cdf;
@@ -631,10 +632,14 @@ ERD F3 DisneyEval(const HitData& hd, F3 V, F3 N, F3 L) {   // src/Disney.cpp:160
 }
 
 // ---- generateHitData, src/kernel.cpp:76-172 ----------------------------------------
-template <bool COUNT>
+// FUSE = false compiles the fused-texel path out: the streaming kernel has an instance of its own for scenes in which no material is
+// fused (C2, C4), whose shading step is then the code it was before -- with the path compiled in, C2 ran 0.4 ... 0.6 % slower for a
+// branch it never takes (register allocation of the whole kernel; profiles/r04_ab_fused_path_on_untextured_scenes.log).
+template <bool COUNT, bool FUSE = true>
 ERD void generate_hit_data(const DevScene& S, const ErMaterial& mat, const HitFull& hit, HitData& hd, unsigned& texels) {
-    const DevFused fu = S.mat_fused[hit.material];
-    const bool fused = fu.width > 0;      // albedo, roughness and metallic of this material come from one fused texel
+    DevFused fu = {0, 0, 0, 0};
+    if (FUSE && S.fused_any) fu = S.mat_fused[hit.material];
+    const bool fused = FUSE && fu.width > 0;      // albedo, roughness and metallic of this material come from one fused texel
     F3 fu_rm = f3s(0);
     if (fused) { fused_fetch(S, fu, hit.tu, hit.tv, hd.albedo, fu_rm); if (COUNT) texels += 3; }
     else if (mat.albedo_tex < 0) hd.albedo = f3(mat.albedo.x, mat.albedo.y, mat.albedo.z);

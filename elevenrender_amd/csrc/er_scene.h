@@ -177,6 +177,7 @@ struct ErScene {
     DevBuf<float> d_tex_pool, d_cdf;
     DevBuf<uint32_t> d_samples, d_rng, d_owned;
     DevBuf<DevCounters> d_counters;
+    bool fused_any = false;          // some material's textures are fused
     DevBuf<DevFused> d_mat_fused;   // per material: its fused albedo / roughness / metallic texels in d_tex_pool, or width 0
     DevBuf<DevScene> d_dev;      // device copy of `dev`: the streaming kernel reads the scene descriptor through a pointer
     DevBuf<float4> d_wf4;        // 11 float4 arrays of the wavefront state, back to back

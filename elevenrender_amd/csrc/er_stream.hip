@@ -280,7 +280,7 @@ __device__ __forceinline__ void st_write_result(const StState& W, uint32_t rec, 
 
 }  // namespace
 
-template <bool COUNT, bool EXT, uint32_t ST_THREADS>
+template <bool COUNT, bool EXT, uint32_t ST_THREADS, bool FUSE>
 __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __attribute__((address_space(4)))* Sp, StState W, const uint32_t* deal, uint32_t deal_count, uint2* ring_base, uint32_t ring_cap,
                                                           uint32_t* status, uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min, uint32_t fin_min) {
     // The scene descriptor lives in constant memory and is read with scalar loads where it is used.  As a by-value kernel argument its
@@ -649,6 +649,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     W.aov_n(slot) = make_float4((n).x, (n).y, (n).z, 0.0f);                                                      \
     W.aov_t(slot) = make_float4((t).x, (t).y, (t).z, 0.0f);                                                      \
     W.aov_b(slot) = make_float4((b).x, (b).y, (b).z, 0.0f)
+#define ER_BOUNCE_FUSE FUSE
 #include "er_bounce.inc"
 #undef ER_BOUNCE_HDRI_QUERY
 #undef ER_BOUNCE_LIGHT_QUERY
@@ -864,8 +865,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
 hipError_t er_probe_stream(const char** which) {
     hipFuncAttributes a;
     *which = "er_stream_kernel";
-    hipError_t e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 1024u>);
-    return e != hipSuccess ? e : hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 768u>);
+    hipError_t e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 1024u, false>);
+    return e != hipSuccess ? e : hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 768u, true>);
 }
 
 // Which workgroup renders which tiles.  Workgroups b and b + 8 run on the same XCD and share its 4 MB L2 (observed dispatch
@@ -945,8 +946,13 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
     if (tracers > waves - 1u) tracers = waves - 1u;      // at least one shader wave
     if (tracers < 1u) tracers = 1u;
     const bool ext = er_ext_active(S);
-    auto k16 = count ? (ext ? er_stream_kernel<true, true, 1024u> : er_stream_kernel<true, false, 1024u>) : (ext ? er_stream_kernel<false, true, 1024u> : er_stream_kernel<false, false, 1024u>);
-    auto k12 = count ? (ext ? er_stream_kernel<true, true, 768u> : er_stream_kernel<true, false, 768u>) : (ext ? er_stream_kernel<false, true, 768u> : er_stream_kernel<false, false, 768u>);
+    // (FUSE: an instance without the fused-texel path for scenes in which no material is fused, er_device.h generate_hit_data)
+    const bool fuse = S.fused_any != 0u;
+    auto pick = [&](auto with, auto without) { return fuse ? with : without; };
+    auto k16 = count ? (ext ? pick(er_stream_kernel<true, true, 1024u, true>, er_stream_kernel<true, true, 1024u, false>) : pick(er_stream_kernel<true, false, 1024u, true>, er_stream_kernel<true, false, 1024u, false>))
+                     : (ext ? pick(er_stream_kernel<false, true, 1024u, true>, er_stream_kernel<false, true, 1024u, false>) : pick(er_stream_kernel<false, false, 1024u, true>, er_stream_kernel<false, false, 1024u, false>));
+    auto k12 = count ? (ext ? pick(er_stream_kernel<true, true, 768u, true>, er_stream_kernel<true, true, 768u, false>) : pick(er_stream_kernel<true, false, 768u, true>, er_stream_kernel<true, false, 768u, false>))
+                     : (ext ? pick(er_stream_kernel<false, true, 768u, true>, er_stream_kernel<false, true, 768u, false>) : pick(er_stream_kernel<false, false, 768u, true>, er_stream_kernel<false, false, 768u, false>));
     StState st;
     st.base = (char*)records;
     st.spill = (uint2*)spill;
