@@ -6,6 +6,7 @@
 #include <chrono>
 
 #include "er_scene.h"
+#include <thread>
 
 using namespace erh;
 
@@ -282,19 +283,45 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     const bool compact = !(compact_knob && atoi(compact_knob) == 0);
     std::vector<DevTex> table(s->textures.size());
     std::vector<float> pool;
+    const bool pow_on_host = !getenv("ER_MAT_PRE_ON_DEVICE");
+    // mode per texture: 0 as it came, 1 first channel alone, 2 first channel alone to the power 2.2; the one-channel copies are made by a
+    // few threads (C5: 8.4 M er_pow, ~0.2 s on one core) and appended in order
+    std::vector<uint8_t> mode(s->textures.size(), 0);
     for (size_t i = 0; i < s->textures.size(); i++) {
         const HostTex& t = s->textures[i];
         if (compact && t.channels >= 1 && scal_use[i] && !vec_use[i]) {
-            const bool powered = t.filter != 1 && !plain_use[i] && !getenv("ER_MAT_PRE_ON_DEVICE");
-            if (t.channels > 1 || powered) {
-                table[i] = DevTex{t.width, t.height, 1, powered ? 2 : (t.filter == 1 ? 1 : 0), (uint32_t)pool.size()};
+            const bool powered = t.filter != 1 && !plain_use[i] && pow_on_host;
+            if (t.channels > 1 || powered) mode[i] = powered ? 2 : 1;
+        }
+    }
+    std::vector<std::vector<float>> one(s->textures.size());
+    {
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t i = next.fetch_add(1); i < s->textures.size(); i = next.fetch_add(1)) {
+                if (!mode[i]) continue;
+                const HostTex& t = s->textures[i];
                 const size_t n = (size_t)t.width * (size_t)t.height;
+                one[i].resize(n);
                 for (size_t k = 0; k < n; k++) {
                     const float v = t.data[k * (size_t)t.channels];
-                    pool.push_back(powered ? ermath::er_pow(v, 2.2f) : v);
+                    one[i][k] = mode[i] == 2 ? ermath::er_pow(v, 2.2f) : v;
                 }
-                continue;
             }
+        };
+        const unsigned nt = std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<std::thread> th;
+        for (unsigned k = 1; k < nt; k++) th.emplace_back(work);
+        work();
+        for (auto& x : th) x.join();
+    }
+    for (size_t i = 0; i < s->textures.size(); i++) {
+        const HostTex& t = s->textures[i];
+        if (mode[i]) {
+            table[i] = DevTex{t.width, t.height, 1, mode[i] == 2 ? 2 : (t.filter == 1 ? 1 : 0), (uint32_t)pool.size()};
+            pool.insert(pool.end(), one[i].begin(), one[i].end());
+            std::vector<float>().swap(one[i]);
+            continue;
         }
         table[i] = DevTex{t.width, t.height, t.channels, t.filter == 1 ? 1 : 0, (uint32_t)pool.size()};      // (anything but BILINEAR fetches unfiltered, src/Texture.cpp:229-236; 2 is the library's own mark)
         pool.insert(pool.end(), t.data.begin(), t.data.end());
@@ -316,19 +343,22 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             if (A.width != R.width || A.width != K.width || A.height != R.height || A.height != K.height) continue;
             if ((A.filter == 1) != (R.filter == 1) || (A.filter == 1) != (K.filter == 1)) continue;
             if (A.channels < 1 || R.channels < 1 || K.channels < 1) continue;
-            const bool bilinear = A.filter == 1, powered = !bilinear && !getenv("ER_MAT_PRE_ON_DEVICE");
+            const bool bilinear = A.filter == 1, powered = !bilinear && pow_on_host;
             const size_t n = (size_t)A.width * (size_t)A.height;
             if (pool.size() + 5 * n >= (1ull << 32)) continue;
             fused[m] = DevFused{A.width, A.height, bilinear ? 1 : (powered ? 2 : 0), (uint32_t)pool.size()};
+            // (a texture the pass above already raised to the power is copied from the pool, not raised again: C5's 8.4 M texels)
+            const DevTex tr = table[(size_t)ids[1]], tk = table[(size_t)ids[2]];
+            const bool r_done = powered && tr.filter == 2, k_done = powered && tk.filter == 2;
             for (size_t k = 0; k < n; k++) {
                 const float* a = A.data.data() + k * (size_t)A.channels;
-                const float r = R.data[k * (size_t)R.channels], mt = K.data[k * (size_t)K.channels];
+                const float r = r_done ? pool[tr.offset + k] : R.data[k * (size_t)R.channels], mt = k_done ? pool[tk.offset + k] : K.data[k * (size_t)K.channels];
                 // (one channel: the value three times; two: x, y, 0; three or more: the first three -- src/Texture.cpp:181-197)
                 pool.push_back(a[0]);
                 pool.push_back(A.channels == 1 ? a[0] : a[1]);
                 pool.push_back(A.channels == 1 ? a[0] : (A.channels == 2 ? 0.0f : a[2]));
-                pool.push_back(powered ? ermath::er_pow(r, 2.2f) : r);
-                pool.push_back(powered ? ermath::er_pow(mt, 2.2f) : mt);
+                pool.push_back(powered && !r_done ? ermath::er_pow(r, 2.2f) : r);
+                pool.push_back(powered && !k_done ? ermath::er_pow(mt, 2.2f) : mt);
             }
         }
     }
