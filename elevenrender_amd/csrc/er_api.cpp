@@ -7,6 +7,7 @@
 
 #include "er_scene.h"
 #include <thread>
+#include <system_error>
 
 using namespace erh;
 
@@ -294,15 +295,19 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             if (t.channels > 1 || powered) mode[i] = powered ? 2 : 1;
         }
     }
+    s->tex_mode = mode;
     std::vector<std::vector<float>> one(s->textures.size());
+    // (sized HERE, on the calling thread: a std::bad_alloc then unwinds into guarded() -> ER_ERR_OOM; thrown inside a worker it
+    // would be an uncaught exception of that thread, i.e. std::terminate.  The workers below only compute.)
+    for (size_t i = 0; i < s->textures.size(); i++)
+        if (mode[i]) one[i].resize((size_t)s->textures[i].width * (size_t)s->textures[i].height);
     {
         std::atomic<size_t> next{0};
-        auto work = [&]() {
+        auto work = [&]() noexcept {
             for (size_t i = next.fetch_add(1); i < s->textures.size(); i = next.fetch_add(1)) {
                 if (!mode[i]) continue;
                 const HostTex& t = s->textures[i];
-                const size_t n = (size_t)t.width * (size_t)t.height;
-                one[i].resize(n);
+                const size_t n = one[i].size();
                 for (size_t k = 0; k < n; k++) {
                     const float v = t.data[k * (size_t)t.channels];
                     one[i][k] = mode[i] == 2 ? ermath::er_pow(v, 2.2f) : v;
@@ -310,10 +315,19 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             }
         };
         const unsigned nt = std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-        std::vector<std::thread> th;
-        for (unsigned k = 1; k < nt; k++) th.emplace_back(work);
+        // (joined by a scope guard: if a std::thread constructor throws while earlier workers run, they are joined before the
+        // exception leaves this block -- a joinable thread destroyed is std::terminate -- and the work they did not get to is done here)
+        struct JoinAll {
+            std::vector<std::thread> th;
+            ~JoinAll() { for (auto& x : th) if (x.joinable()) x.join(); }
+        } pool_threads;
+        pool_threads.th.reserve(nt);
+        try {
+            for (unsigned k = 1; k < nt; k++) pool_threads.th.emplace_back(work);
+        } catch (const std::system_error&) {
+            // fewer workers than asked for: the calling thread takes what is left
+        }
         work();
-        for (auto& x : th) x.join();
     }
     for (size_t i = 0; i < s->textures.size(); i++) {
         const HostTex& t = s->textures[i];
@@ -454,6 +468,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         if (const char* e = getenv("ER_STREAM_WAVES")) { s->stream_waves = atoi(e) == 12 ? 12 : 16; s->stream_tracers = s->stream_waves == 12 ? 9u : ((lights_on || s->tri_count > 4000000u) ? 12u : 13u); }   // A/B knob
         if (const char* e = getenv("ER_STREAM_TRACERS")) { s->stream_tracers = (uint32_t)std::min(13, std::max(1, atoi(e))); s->stream_adapt = false; }   // tuning knob: fixed split
         if (const char* e = getenv("ER_STREAM_ADAPT")) s->stream_adapt = atoi(e) != 0;
+        s->stream_tracers_start = s->stream_tracers; s->stream_low_streak = 0; s->stream_up_budget = 1;
         const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
         if ((rc = upload(s->d_wf4, nullptr, slots * er_stream_record_bytes(lights_on) / sizeof(float4), s->stream)) != ER_OK) return rc;
         if ((rc = upload(s->d_wf1, nullptr, 24, s->stream)) != ER_OK) return rc;       // [1] status word, [2..5] the tracers' lane occupancy, [6..23] start / end per XCD
@@ -746,6 +761,7 @@ int er_scene_stream_status(ErScene* s, const char* who) {
     unsigned long long lo = ~0ull, hi = 0;
     for (int x = 0; x < 8; x++) { const unsigned long long e = u64(8 + 2 * x); lo = std::min(lo, e); hi = std::max(hi, e); }
     s->stream_xcd_spread = (t0 != ~0ull && lo > t0 && hi - t0 >= 200000ull) ? (double)(hi - lo) / (double)(hi - t0) : -1.0;
+    s->stream_launch_ms = (t0 != ~0ull && hi > t0) ? (double)(hi - t0) * 1e-5 : 0.0;
     return ER_OK;
 }
 
@@ -754,8 +770,11 @@ int er_scene_stream_status(ErScene* s, const char* who) {
 // operations per iteration): clearly not full = the shader waves cannot produce rays fast enough, and one tracer wave becomes a
 // shader wave for the next call.  Measured with the product kernel (profiles/r04_sweep_split_after_shader_diet.log): C2 0.89-0.90 full
 // at 13 + 3 (its best split); C4 0.81-0.85 at 13 + 3 and 0.92 at 12 + 4 (its best); C5 with lights 0.75 at 13 + 3, 0.90 at 12 + 4 (its
-// best).  Lanes that ARE full say nothing (C4 looks alike at 12 + 4 and 11 + 5), so the split only ever moves this way: one wave per
-// completed call while the lanes are under 0.85 full, down to 10 + 6 (7 + 5 of 12 waves).  The image does not depend on the split.
+// best).  Lanes that ARE full say little (C4 looks alike at 12 + 4 and 11 + 5), so the split moves down: one wave after TWO
+// consecutive calls whose lanes were under 0.85 full, down to 10 + 6 (7 + 5 of 12 waves).  A call shorter than ER_STREAM_ADAPT_MIN_MS
+// of device time is not a reading at all (its lanes are mostly ramp-up and tail: a 1-spp preview would otherwise walk the split
+// down for good), and ONE step back up is allowed per render when a later call reads above 0.93 (a demotion caused by two
+// unrepresentative calls is undone; a second demotion after that stays).  The image does not depend on the split.
 static void er_stream_adapt(ErScene* s) {
     const bool verbose = getenv("ER_STREAM_VERBOSE") != nullptr;      // (read per call: a test turns it on for one render)
     if (s->stream_adapted == s->stream_launches) return;              // (a second er_wait after the same launch: its measurements have been used)
@@ -775,7 +794,16 @@ static void er_stream_adapt(ErScene* s) {
     if (!s->stream_adapt || !(s->params.flags & ER_FLAG_STREAM) || s->stream_busy <= 0.0) return;
     const uint32_t lo = s->stream_waves == 12 ? 7u : 10u;
     const uint32_t before = s->stream_tracers;
-    if (s->stream_busy < 0.85 && s->stream_tracers > lo) s->stream_tracers--;
+    if (s->stream_launch_ms < ER_STREAM_ADAPT_MIN_MS) {
+        if (verbose) fprintf(stderr, "[er_stream] tracer lanes %.3f full in a launch of %.2f ms: too short to be a reading\n", s->stream_busy, s->stream_launch_ms);
+        return;
+    }
+    if (s->stream_busy < 0.85) {
+        if (++s->stream_low_streak >= 2u && s->stream_tracers > lo) { s->stream_tracers--; s->stream_low_streak = 0; }
+    } else {
+        s->stream_low_streak = 0;
+        if (s->stream_busy > 0.93 && s->stream_up_budget > 0u && s->stream_tracers < s->stream_tracers_start) { s->stream_tracers++; s->stream_up_budget--; }
+    }
     if (verbose) fprintf(stderr, "[er_stream] tracer lanes %.3f full at %u + %u waves -> %u + %u\n", s->stream_busy, before, s->stream_waves - before, s->stream_tracers, s->stream_waves - s->stream_tracers);
 }
 

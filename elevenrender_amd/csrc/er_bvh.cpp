@@ -355,7 +355,6 @@ void er_collapse_bvh8(ErBvhBuild* out) {
         }
         nd.child_base = (uint32_t)out->nodes8.size();
         nd.tri_base = (uint32_t)new_order.size();
-        uint32_t tri_off = 0;
         for (int s8 = 0; s8 < 8; s8++) {
             int ci = child_in[s8];
             if (ci < 0) continue;
@@ -382,7 +381,6 @@ void er_collapse_bvh8(ErBvhBuild* out) {
                 nd.tri_present |= ((1u << count) - 1u) << (2 * s8);
                 uint32_t new_first = (uint32_t)new_order.size();
                 for (uint32_t i = 0; i < count; i++) new_order.push_back(first + i);
-                tri_off += count;
                 shift_leaves(c.parent2, c.which, c.ref, (int64_t)new_first - (int64_t)first);   // keep the binary tree valid
             }
         }

@@ -197,6 +197,11 @@ static int er_debug_eval_impl(ErScene* s, int kind, const float* in, uint32_t n,
             int32_t id;
             memcpy(&id, &in[(size_t)i * in_stride], 4);
             if (id < -1 || id >= (int32_t)s->textures.size()) return fail(ER_ERR_INVALID_ARG, "er_debug_eval: texture id out of range");
+            // The device table may hold a scalar-only texture with its first channel alone, possibly already to the power 2.2
+            // (er_render_begin): a fetch from that entry is not a fetch from the scene's texture, so it is refused, not answered.
+            if (id >= 0 && (size_t)id < s->tex_mode.size() && s->tex_mode[(size_t)id] != 0)
+                return fail(ER_ERR_STATE, "er_debug_eval: texture " + std::to_string(id) + " is kept compacted on the device (first channel" +
+                                              (s->tex_mode[(size_t)id] == 2 ? ", to the power 2.2" : "") + "); begin the render with ER_TEX_COMPACT=0 to evaluate ER_FN_TEXTURE on it");
         }
     HIP_TRY(hipSetDevice(s->device));
     ScopedDevBuf<float> d_in, d_out;

@@ -34,6 +34,7 @@
 #include <stdint.h>
 
 #ifdef ER_RING_HOST_MODEL
+#include <chrono>
 #include <thread>
 #define ER_RING_FN static inline
 ER_RING_FN uint32_t er_ring_load(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
@@ -51,7 +52,14 @@ ER_RING_FN unsigned long long er_ring_cas64(unsigned long long* p, unsigned long
     __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
     return expect;
 }
-ER_RING_FN void er_ring_pause() { std::this_thread::yield(); }
+// (a waiter yields; every 1024th poll of a thread it sleeps a millisecond instead, so that on an oversubscribed machine -- the CPU
+// suite beside a compile job -- the thread it waits for gets its core long before the poll guard expires: round 5 saw a correct run
+// of the model end in "put guard expired" under exactly that load)
+ER_RING_FN void er_ring_pause() {
+    static thread_local uint32_t polls = 0;
+    if ((++polls & 1023u) == 0u) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    else std::this_thread::yield();
+}
 #else
 #include <hip/hip_runtime.h>
 #define ER_RING_FN __device__ __forceinline__

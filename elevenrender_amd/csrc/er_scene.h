@@ -177,6 +177,7 @@ struct ErScene {
     DevBuf<float> d_tex_pool, d_cdf;
     DevBuf<uint32_t> d_samples, d_rng, d_owned;
     DevBuf<DevCounters> d_counters;
+    std::vector<uint8_t> tex_mode;   // per texture, how the device table holds it: 0 as it came, 1 first channel alone, 2 first channel alone to the power 2.2 (er_render_begin)
     bool fused_any = false;          // some material's textures are fused
     DevBuf<DevFused> d_mat_fused;   // per material: its fused albedo / roughness / metallic texels in d_tex_pool, or width 0
     DevBuf<DevScene> d_dev;      // device copy of `dev`: the streaming kernel reads the scene descriptor through a pointer
@@ -190,6 +191,8 @@ struct ErScene {
     uint32_t* stream_ctl = nullptr;                     //   [0] pixel ticket, [1] status word, [2..3] tracer iterations, [4..5] busy tracer lanes of the last call, [6..7] its start, [8..23] its end per XCD (100 MHz)
     bool stream_adapt = false;                          //   move a wave between the roles by how full the tracer lanes were (er_stream_adapt)
     double stream_busy = 0.0;                           //   tracer lanes that held a ray, last completed call
+    double stream_launch_ms = 0.0;                      //   device time of that call's launch (start stamp to the last XCD's end stamp)
+    uint32_t stream_low_streak = 0, stream_up_budget = 1, stream_tracers_start = 0;   //   er_stream_adapt: consecutive low readings; steps back up left; the split the render began with
     uint32_t stream_deal_off = 0, stream_deal_n = 0;    //   the deal in use inside d_deal (entries): the one of large super-tiles first, the default edge's after it
     uint32_t stream_deal_alt_off = 0, stream_deal_alt_n = 0;   //   the fallback deal (0 entries: none), taken when the XCDs of a call finished too far apart
     double stream_xcd_spread = 0.0;                     //   (latest - earliest XCD) / launch duration of the last completed call; < 0: not measured
@@ -220,7 +223,7 @@ struct ErScene {
     void release_device() {
         d_nodes.release(); d_nodes8.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_plane.release(); d_materials.release();
         d_textures.release(); d_tex_pool.release(); d_lights.release(); d_cdf.release(); d_samples.release(); d_rng.release();
-        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_deal.release(); d_ray_log.release(); d_mat_fused.release();
+        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_deal.release(); d_ray_log.release(); d_mat_fused.release(); d_mat_pre.release(); d_dev.release();
         for (auto& kv : d_rank_tiles) kv.second.release();
         d_rank_tiles.clear();
         for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);

@@ -24,6 +24,9 @@ struct WfState;
                                           // to one side: fewer, larger regions per XCD sample the cost too coarsely), so the library keeps it only while the XCDs of a
                                           // call finish within ER_STREAM_XCD_SPREAD_MAX of each other (er_api.cpp er_stream_adapt; profiles/r04_sweep_super_tile.log)
 #endif
+#ifndef ER_STREAM_ADAPT_MIN_MS
+#define ER_STREAM_ADAPT_MIN_MS 4.0       // a launch shorter than this (device time) is no reading of the tracer lanes' occupancy: start-up and tail dominate it
+#endif
 #ifndef ER_STREAM_XCD_SPREAD_MAX
 #define ER_STREAM_XCD_SPREAD_MAX 0.10     // (measured: 0.02 ... 0.09 on every deal of every frame tried -- the XCDs never finish together -- 0.15 and 0.32 on large regions of uneven cost)
 #endif

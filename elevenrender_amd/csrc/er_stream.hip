@@ -488,7 +488,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                     stt.tri = st.tri && do_tri;
                     occl = trav_apply_tri<COUNT>(T, S, stt, D, c_tris);
                     trav_wait_node(R, D);
-                    if (top) { const float4* q = s_top + (ER_NODE8_PIECES == 5 ? st.noff : st.noff / (uint32_t)ER_NODE8_PIECES * 5u); D.n0 = q[0]; D.n1 = q[1]; D.n2 = q[2]; D.n3 = q[3]; D.n4 = q[4]; }
+                    if (top) trav_node_from_lds(D, s_top, st.noff);
                     TravStep sn = st;
                     sn.node = st.node && do_tri && !occl;
                     trav_apply_node<COUNT>(T, S, sn, D, c_nodes);
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                     TravStep sg = st;
                     if (top) sg.node = false;          // (these lanes' node loads go to the shared dummy address)
                     trav_fetch(S, sg, D);
-                    if (top) { const float4* q = s_top + (ER_NODE8_PIECES == 5 ? st.noff : st.noff / (uint32_t)ER_NODE8_PIECES * 5u); D.n0 = q[0]; D.n1 = q[1]; D.n2 = q[2]; D.n3 = q[3]; D.n4 = q[4]; }
+                    if (top) trav_node_from_lds(D, s_top, st.noff);
                 }
                 ER_MARK("tracer_apply");
                 bool occl = false;

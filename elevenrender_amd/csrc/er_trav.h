@@ -161,7 +161,8 @@ ERD void trav_fetch(const DevScene& S, const TravStep& st, TravData& D) {
 // destination register is an in/out operand ("+v") of the statement that waits for it: that keeps all four components of a piece
 // live from its load to its wait, so the allocator can neither park another value in an unused component nor copy or spill a
 // register whose load has not landed (tools/check_split_wait.py reads the device assembly and fails the build check if any
-// instruction between a load and its wait names one of its destination registers).
+// instruction between a load and its wait names one of its destination registers; the Makefile runs it on every build of er_stream.o and
+// a failing build has no object; the marker's "tri=" / "node=" say how many loads of each kind the statement holds).
 typedef float F4V __attribute__((ext_vector_type(4)));      // (a native vector: an in/out asm operand cannot be the float4 struct)
 struct TravRaw { F4V n0, n1, n2, n3, n4, a, b4, c, dd, e4, f4; };
 ERD float4 f4_of(F4V v) { return make_float4(v.x, v.y, v.z, v.w); }
@@ -169,7 +170,7 @@ ERD void trav_fetch_issue(const DevScene& S, const TravStep& st, TravRaw& R) {
     const float4* pn = S.nodes8 + (st.node ? st.noff : 0u);
     const float4* pt = S.nodes8 + (st.tri ? st.toff : 0u);
     const float4* pt2 = (st.tri && st.two) ? pt : S.nodes8;
-    asm volatile("; ER_SPLIT issue\n\t"
+    asm volatile("; ER_SPLIT issue tri=6 node=5\n\t"
                  "global_load_dwordx4 %5, %12, off\n\t"
                  "global_load_dwordx4 %6, %12, off offset:16\n\t"
                  "global_load_dwordx4 %7, %12, off offset:32\n\t"
@@ -196,6 +197,13 @@ ERD void trav_wait_tri(TravRaw& R, TravData& D) {
 ERD void trav_wait_node(TravRaw& R, TravData& D) {
     asm volatile("; ER_SPLIT wait_node\n\ts_waitcnt vmcnt(0)" : "+v"(R.n0), "+v"(R.n1), "+v"(R.n2), "+v"(R.n3), "+v"(R.n4) : : "memory");
     D.n0 = f4_of(R.n0); D.n1 = f4_of(R.n1); D.n2 = f4_of(R.n2); D.n3 = f4_of(R.n3); D.n4 = f4_of(R.n4);
+}
+
+// the top of the tree from its LDS copy (streaming schedule): the five pieces of the node at piece offset `noff` replace what the
+// global loads brought (those lanes' loads went to the shared dummy address)
+ERD void trav_node_from_lds(TravData& D, const float4* s_top, uint32_t noff) {
+    const float4* q = s_top + (ER_NODE8_PIECES == 5 ? noff : noff / (uint32_t)ER_NODE8_PIECES * 5u);
+    D.n0 = q[0]; D.n1 = q[1]; D.n2 = q[2]; D.n3 = q[3]; D.n4 = q[4];
 }
 
 // phase 3, TRIANGLE part.  Returns true when a shadow query found a certain occluder (the ray is then complete).

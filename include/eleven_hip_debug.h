@@ -85,6 +85,9 @@ int er_debug_trace_pixel(struct ErScene* scene, uint32_t idx, ErTraceRec* recs, 
  *   ER_FN_SPHERICAL      in [p(3)]                                     out [u, v]                                 (2)
  *   ER_FN_REV_SPHERICAL  in [u, v]                                     out [p(3)]                                 (3)
  *   ER_FN_TEXTURE        in [bits(texture id, -1 = the HDRI), u, v, filtered(0/1)]   out [rgb]                    (3)
+ *                        (ER_ERR_STATE for a texture the library keeps compacted on the device -- one channel, possibly to the
+ *                        power 2.2, er_render_begin -- since a fetch from that entry is not a fetch from the scene's texture;
+ *                        begin the render with ER_TEX_COMPACT=0 in the environment to evaluate such a texture)
  *   ER_FN_HDRI_SEARCH    in [value]                                    out [bits(index)]                          (1)
  *   ER_FN_HDRI_PDF       in [bits(x), bits(y)]                         out [pdf]                                  (1)
  *   ER_FN_MATH           in [bits(op: 0 sin 1 cos 2 acos 3 log 4 pow 5 atan2), x, y]   out [value]                (1) */

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
-"""Checks the device assembly of er_stream.hip built with -DER_STREAM_SPLIT_WAIT=1: between the statement that issues the eleven
-loads of a traversal step ("; ER_SPLIT issue") and the statements that wait for them ("wait_tri": the six triangle pieces, "wait_node":
-the five node pieces) no instruction may name a destination register of a load that has not been waited for -- the compiler does not
+"""Checks the device assembly of er_stream.hip built with -DER_STREAM_SPLIT_WAIT=1: between the statement that issues the
+loads of a traversal step ("; ER_SPLIT issue tri=T node=N") and the statements that wait for them ("wait_tri": the T triangle pieces,
+"wait_node": the N node pieces) no instruction may name a destination register of a load that has not been waited for -- the compiler does not
 know those loads are in flight (cdna_hip_programming.md 5.7 item 1), so a copy, spill or reuse there would be silent corruption.
 
-    python tools/check_split_wait.py file.s        exit code 0 = every occurrence is clean
+    python tools/check_split_wait.py file.s        exit code 0 = every occurrence is clean (and there is at least one)
+The Makefile runs it on every build of er_stream.o and deletes the object when it fails.
 """
 import re
 import sys
@@ -39,8 +40,11 @@ def main():
         while "global_load_dwordx4" in lines[j]:
             loads.append(regs_of(lines[j].split()[1].rstrip(",")))
             j += 1
-        assert len(loads) == 11, (i, len(loads))
-        tri, node = set().union(*loads[:6]), set().union(*loads[6:])
+        # the marker says how many loads of each kind the statement holds ("tri=6 node=4"; eleven loads, six first, without it)
+        m = re.search(r"tri=(\d+) node=(\d+)", lines[i])
+        n_tri, n_node = (int(m.group(1)), int(m.group(2))) if m else (6, 5)
+        assert len(loads) == n_tri + n_node, (i, len(loads), n_tri, n_node)
+        tri, node = set().union(*loads[:n_tri]), set().union(*loads[n_tri:])
         pending = tri | node
         k = j
         state = "tri"

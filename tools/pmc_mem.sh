@@ -9,7 +9,7 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 pass() {
   name=$1; shift
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/$name -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-trace-phase > $out/$name.log 2>&1 || echo "pass $name failed"
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $out/$name -o run -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-trace-phase > $out/$name.log 2>&1 || { echo "pass $name FAILED (see $out/$name.log)"; exit 1; }
   echo "pass $name done"
 }
 pass ta TA_BUSY_avr TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE
