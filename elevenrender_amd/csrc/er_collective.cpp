@@ -217,8 +217,8 @@ static int er_gather_pass_impl(ErScene* s, int pass, ErComm* c, uint32_t root) {
     int rc;
     if (c->rank != root) {
         const size_t n = (size_t)s->dev.owned_tile_count * 64;
-        ScopedDevBuf<float4> mine;
-        if ((rc = upload(mine, (const float4*)nullptr, n, st)) != ER_OK) return rc;
+        DevBuf<float4>& mine = s->d_gather_mine;          // (kept on the scene: allocated by the first gather)
+        if (mine.n < n || !mine.p) { if ((rc = upload(mine, (const float4*)nullptr, n, st)) != ER_OK) return rc; }
         er_launch_pack(s->dev, s->d_owned.p, s->dev.owned_tile_count, pass, mine.p, st);
         HIP_TRY(hipGetLastError());
         if ((rc = c->t.group_start(c->self)) != ER_OK) return rc;
@@ -226,23 +226,14 @@ static int er_gather_pass_impl(ErScene* s, int pass, ErComm* c, uint32_t root) {
         int rc2 = c->t.group_end(c->self);
         if (rc != ER_OK) return rc;
         if (rc2 != ER_OK) return rc2;
-        HIP_TRY(hipStreamSynchronize(st));   // `mine` is freed on return
+        HIP_TRY(hipStreamSynchronize(st));   // the next gather packs into the same buffer
         return er_scene_stream_status(s, "er_gather_pass");   // (what was sent is incomplete if the streaming schedule stopped early)
     }
     // root: one receive buffer per peer, all receives in ONE group (seven xGMI links side by side), then the scatters
-    std::vector<ScopedDevBuf<float4>> in(c->world);
+    // (receive buffers and the peers' tile tables live on the scene: the first gather allocates and uploads them, every later one
+    // only packs, receives and scatters)
+    std::vector<float4*> in(c->world, nullptr);
     std::vector<size_t> counts(c->world, 0);
-    for (uint32_t r = 0; r < c->world; r++) {
-        if (r == root) continue;
-        counts[r] = s->tiles_of(r, c->world).size() * 64;
-        if ((rc = upload(in[r], (const float4*)nullptr, counts[r], st)) != ER_OK) return rc;
-    }
-    if ((rc = c->t.group_start(c->self)) != ER_OK) return rc;
-    for (uint32_t r = 0; r < c->world && rc == ER_OK; r++)
-        if (r != root) rc = c->t.recv(c->self, in[r].p, counts[r] * sizeof(float4), r, st);
-    int rc2 = c->t.group_end(c->self);
-    if (rc != ER_OK) return rc;
-    if (rc2 != ER_OK) return rc2;
     for (uint32_t r = 0; r < c->world; r++) {
         if (r == root) continue;
         auto it = s->d_rank_tiles.find(r);
@@ -254,7 +245,21 @@ static int er_gather_pass_impl(ErScene* s, int pass, ErComm* c, uint32_t root) {
             it = s->d_rank_tiles.emplace(r, DevBuf<uint32_t>(b)).first;
             b.p = nullptr;
         }
-        er_launch_unpack(s->dev, it->second.p, (uint32_t)it->second.n, pass, in[r].p, st);
+        counts[r] = it->second.n * 64;
+        DevBuf<float4>& buf = s->d_gather_in[r];
+        if (buf.n < counts[r] || !buf.p) { if ((rc = upload(buf, (const float4*)nullptr, counts[r], st)) != ER_OK) return rc; }
+        in[r] = buf.p;
+    }
+    if ((rc = c->t.group_start(c->self)) != ER_OK) return rc;
+    for (uint32_t r = 0; r < c->world && rc == ER_OK; r++)
+        if (r != root) rc = c->t.recv(c->self, in[r], counts[r] * sizeof(float4), r, st);
+    int rc2 = c->t.group_end(c->self);
+    if (rc != ER_OK) return rc;
+    if (rc2 != ER_OK) return rc2;
+    for (uint32_t r = 0; r < c->world; r++) {
+        if (r == root) continue;
+        const DevBuf<uint32_t>& tiles = s->d_rank_tiles[r];
+        er_launch_unpack(s->dev, tiles.p, (uint32_t)tiles.n, pass, in[r], st);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));

@@ -207,6 +207,11 @@ struct ErScene {
     size_t prof_used = 0;
     ErProfile profile{};
     std::map<uint32_t, DevBuf<uint32_t>> d_rank_tiles;   // tile lists of other ranks (for unpack)
+    // er_gather_pass: the packed owned pixels of this rank (non-root) and one receive buffer per peer (root), allocated at the first
+    // gather and kept for the scene's life -- a read-back of five planes from seven peers was 35 hipMalloc / hipFree pairs inside the
+    // time the gather is measured by; now it is pack + wire + unpack
+    DevBuf<float4> d_gather_mine;
+    std::map<uint32_t, DevBuf<float4>> d_gather_in;
     // which ranks' pixels of each plane were unpacked into this scene since the last sample was enqueued: er_denoise on a
     // sharded frame needs the whole BEAUTY and NORMAL planes (the rank the frame was gathered to)
     std::set<uint32_t> unpacked[ER_PASS_COUNT];
@@ -226,6 +231,9 @@ struct ErScene {
         d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_deal.release(); d_ray_log.release(); d_mat_fused.release(); d_mat_pre.release(); d_dev.release();
         for (auto& kv : d_rank_tiles) kv.second.release();
         d_rank_tiles.clear();
+        d_gather_mine.release();
+        for (auto& kv : d_gather_in) kv.second.release();
+        d_gather_in.clear();
         for (hipEvent_t e : prof_events) (void)hipEventDestroy(e);
         prof_events.clear();
         prof_used = 0;

@@ -7,7 +7,7 @@ libs=$1; reps=$2; shift 2
 out=gpurun_out/ab_libs; mkdir -p $out
 for r in $(seq 1 $reps); do
   for l in $libs; do
-    if ! ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_$l.so timeout -k 10 400 python3 bench.py --no-cpu-baseline --no-trace-phase "$@" > $out/$l.$r.log 2> $out/$l.$r.err; then echo "$l FAILED"; tail -n 5 $out/$l.$r.err; exit 1; fi
+    if ! ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_$l.so timeout -k 10 400 python3 bench.py --no-cpu-baseline --no-trace-phase --no-projection "$@" > $out/$l.$r.log 2> $out/$l.$r.err; then echo "$l FAILED"; tail -n 5 $out/$l.$r.err; exit 1; fi
     python3 -c "
 import json
 d=json.loads(open('$out/$l.$r.log').read().strip().splitlines()[-1]); r=d['roofline']; t=r.get('trace_lanes') or {}

@@ -18,7 +18,7 @@ tag=${1:?tag}; set_=${2:?full|core}; shift 2
 out=gpurun_out/pmc_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-args="--steps 6 --warmup 2 --no-cpu-baseline --no-trace-phase $*"
+args="--steps 6 --warmup 2 --repeats 1 --no-projection --no-cpu-baseline --no-trace-phase $*"
 pass() {
   name=$1; shift
   if [ "$set_" = check ]; then

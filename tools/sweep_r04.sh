@@ -14,7 +14,7 @@ print('$2', d['value'], 'Msamples/s', d['ms_per_step'], 'ms/step', 'lanes', (r.g
 run() {  # name, env assignments..., -- bench args
   name=$1; shift
   envs=(); while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
-  if ! env "${envs[@]}" timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-trace-phase "$@" > $out/$name.log 2> $out/$name.err; then echo "$name FAILED"; tail -n 5 $out/$name.err; exit 1; fi
+  if ! env "${envs[@]}" timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-trace-phase --no-projection "$@" > $out/$name.log 2> $out/$name.err; then echo "$name FAILED"; tail -n 5 $out/$name.err; exit 1; fi
   line $out/$name.log "$name ${envs[*]}"
 }
 if [ "$what" = sim8 ]; then
