@@ -468,7 +468,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         if (const char* e = getenv("ER_STREAM_WAVES")) { s->stream_waves = atoi(e) == 12 ? 12 : 16; s->stream_tracers = s->stream_waves == 12 ? 9u : ((lights_on || s->tri_count > 4000000u) ? 12u : 13u); }   // A/B knob
         if (const char* e = getenv("ER_STREAM_TRACERS")) { s->stream_tracers = (uint32_t)std::min(13, std::max(1, atoi(e))); s->stream_adapt = false; }   // tuning knob: fixed split
         if (const char* e = getenv("ER_STREAM_ADAPT")) s->stream_adapt = atoi(e) != 0;
-        s->stream_tracers_start = s->stream_tracers; s->stream_low_streak = 0; s->stream_up_budget = 1;
+        s->stream_tracers_start = s->stream_tracers; s->stream_low_streak = 0; s->stream_up_budget = 1; s->stream_readings = 0;
         const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
         if ((rc = upload(s->d_wf4, nullptr, slots * er_stream_record_bytes(lights_on) / sizeof(float4), s->stream)) != ER_OK) return rc;
         if ((rc = upload(s->d_wf1, nullptr, 24, s->stream)) != ER_OK) return rc;       // [1] status word, [2..5] the tracers' lane occupancy, [6..23] start / end per XCD
@@ -488,19 +488,29 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         s->stream_deal_alt_off = 0; s->stream_deal_alt_n = 0;
         s->stream_xcd_spread = -1.0;
         // Larger screen regions per XCD are faster where a frame's cost is even and slower where it is not (er_stream.h), and only the run
-        // can tell which: with the knob unset a render starts on the deal of ER_STREAM_SUPER_TILE_LARGE and keeps the default edge's deal
-        // beside it in d_deal; er_stream_adapt switches to that one, for good, after a call whose XCDs finished too far apart.
+        // can tell which.  With the knob unset a render STARTS on the default deal -- it spreads any frame's cost over the XCDs -- and keeps
+        // the deal of ER_STREAM_SUPER_TILE_LARGE beside it in d_deal; during the first call the kernel adds every finished path's length to
+        // its tile's sum (DevScene::tile_cost: counted work, not a measured time), and er_stream_adapt takes the large regions, for good,
+        // if under THAT deal the XCDs' shares of the counted work are within ER_STREAM_COST_SPREAD_MAX of each other.  (Round 4 started
+        // on the large deal and fell back on the XCDs' measured finish times: an uneven frame paid 8-18 % for its first call, and the
+        // decision -- and the test of it -- hung on clocks.)
         const char* adapt_knob = getenv("ER_STREAM_ADAPT");
+        s->stream_deal_pending = false;
+        s->stream_deal_large.clear();
+        s->d_tile_cost.release();
         if (xcd_aware && s->stream_blocks % 8u == 0u && owned.size() * 64 / s->stream_blocks >= ER_STREAM_SLOTS * 3u / 2u && !(p->flags & ER_FLAG_COUNTERS) &&      // (a half / a quarter of a 1080p frame: +1.2 % / +0.7 %)
             !getenv("ER_STREAM_SUPER_TILE") && !(adapt_knob && atoi(adapt_knob) == 0)) {
             std::vector<uint32_t> large;
             const uint32_t most_large = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), tiles_x, s->stream_blocks, xcd_aware, large, ER_STREAM_SUPER_TILE_LARGE);
             if ((size_t)most_large * 64u <= ER_STREAM_MAX_RING) {      // (levelled, the two deals have the same largest share; never let the optional one fail the call)
-                s->stream_deal_alt_off = (uint32_t)large.size(); s->stream_deal_alt_n = (uint32_t)deal.size();
-                s->stream_deal_n = (uint32_t)large.size();
-                large.insert(large.end(), deal.begin(), deal.end());
-                deal.swap(large);
+                s->stream_deal_alt_off = (uint32_t)deal.size(); s->stream_deal_alt_n = (uint32_t)large.size();
+                deal.insert(deal.end(), large.begin(), large.end());
                 most = std::max(most, most_large);
+                s->stream_deal_large.swap(large);
+                const size_t n_tiles = (size_t)tiles_x * ((s->y_res + ER_TILE - 1) / ER_TILE);
+                if ((rc = upload(s->d_tile_cost, nullptr, n_tiles, s->stream)) != ER_OK) return rc;
+                HIP_TRY(hipMemsetAsync(s->d_tile_cost.p, 0, n_tiles * sizeof(uint32_t), s->stream));
+                s->stream_deal_pending = true;
             }
         }
         if ((rc = upload(s->d_deal, deal.data(), deal.size(), s->stream)) != ER_OK) return rc;
@@ -628,6 +638,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     D.owned_tiles = s->d_owned.p;
     D.owned_tile_count = (uint32_t)owned.size();
     D.counters = s->d_counters.p;
+    D.tile_cost = ((s->params.flags & ER_FLAG_STREAM) && s->stream_deal_pending) ? s->d_tile_cost.p : nullptr;
     {   // the camera's rotation sines / cosines, once, with the functions the device would call (er_math.h: one implementation for both sides)
         const erd::CamTrig t = erd::camera_trig(D.cam);
         D.cam_cx = t.cx; D.cam_sx = t.sx; D.cam_cy = t.cy; D.cam_sy = t.sy; D.cam_cz = t.cz; D.cam_sz = t.sz;
@@ -780,31 +791,60 @@ static void er_stream_adapt(ErScene* s) {
     if (s->stream_adapted == s->stream_launches) return;              // (a second er_wait after the same launch: its measurements have been used)
     s->stream_adapted = s->stream_launches;
     if (verbose && (s->params.flags & ER_FLAG_STREAM) && !s->stream_adapt) fprintf(stderr, "[er_stream] tracer lanes %.3f full at %u + %u waves (fixed split)\n", s->stream_busy, s->stream_tracers, s->stream_waves - s->stream_tracers);
-    // the deal: large screen regions per XCD only while the XCDs finish together (er_stream.h, er_render_begin)
-    if ((s->params.flags & ER_FLAG_STREAM) && s->stream_deal_alt_n && s->stream_xcd_spread >= 0.0) {
-        if (verbose) fprintf(stderr, "[er_stream] XCDs finished %.3f of the launch apart on super-tiles of %u%s\n", s->stream_xcd_spread, (unsigned)ER_STREAM_SUPER_TILE_LARGE,
-                             s->stream_xcd_spread > ER_STREAM_XCD_SPREAD_MAX ? " -> the default deal" : "");
-        if (s->stream_xcd_spread > ER_STREAM_XCD_SPREAD_MAX) {
-            s->stream_deal_off = s->stream_deal_alt_off; s->stream_deal_n = s->stream_deal_alt_n;
-            s->stream_deal_alt_n = 0;
+    // the deal: large screen regions per XCD if the XCDs' shares of the COUNTED work of the first call are alike under them (er_stream.h,
+    // er_render_begin).  Decided once, from counts: the same decision on every run of the same frame.
+    if ((s->params.flags & ER_FLAG_STREAM) && s->stream_deal_pending) {
+        s->stream_deal_pending = false;
+        std::vector<uint32_t> cost(s->d_tile_cost.n);
+        if (hipMemcpy(cost.data(), s->d_tile_cost.p, cost.size() * sizeof(uint32_t), hipMemcpyDeviceToHost) == hipSuccess) {
+            double x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const std::vector<uint32_t>& L = s->stream_deal_large;
+            for (size_t i = 0; i < L.size(); i++)
+                if (L[i] != 0xFFFFFFFFu && L[i] < cost.size()) x[(i % s->stream_blocks) % 8u] += (double)cost[L[i]];      // entry b + k * blocks belongs to workgroup b, XCD b % 8
+            double lo = x[0], hi = x[0], sum = 0;
+            for (double v : x) { lo = std::min(lo, v); hi = std::max(hi, v); sum += v; }
+            const double spread = sum > 0 ? (hi - lo) / (sum / 8.0) : 0.0;
+            const char* lim_env = getenv("ER_STREAM_COST_SPREAD_MAX");      // (test knob, read per decision: 0 keeps the default deal, a large value takes the large one)
+            const double limit = lim_env ? atof(lim_env) : (double)ER_STREAM_COST_SPREAD_MAX;
+            const bool take = sum > 0 && spread <= limit;
+            s->stream_cost_spread = spread;
+            if (verbose) fprintf(stderr, "[er_stream] counted work of the XCDs' shares on super-tiles of %u: %.4f of the mean apart (limit %.4f) -> %s\n", (unsigned)ER_STREAM_SUPER_TILE_LARGE, spread,
+                                 limit, take ? "large regions" : "the default deal stays");
+            if (take) { s->stream_deal_off = s->stream_deal_alt_off; s->stream_deal_n = s->stream_deal_alt_n; }
         }
-    } else if (verbose && (s->params.flags & ER_FLAG_STREAM) && s->stream_xcd_spread >= 0.0) {
-        fprintf(stderr, "[er_stream] XCDs finished %.3f of the launch apart (fixed deal)\n", s->stream_xcd_spread);
+        // the kernel stops counting: the scene descriptor it reads loses the pointer (ordered on the stream before the next launch)
+        s->dev.tile_cost = nullptr;
+        (void)hipMemcpyAsync(s->d_dev.p, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, s->stream);
+        (void)hipStreamSynchronize(s->stream);
+        s->stream_deal_large.clear(); s->stream_deal_large.shrink_to_fit();
     }
+    if (verbose && (s->params.flags & ER_FLAG_STREAM) && s->stream_xcd_spread >= 0.0)
+        fprintf(stderr, "[er_stream] XCDs finished %.3f of the launch apart (a measured time: printed, nothing is decided on it)\n", s->stream_xcd_spread);
     if (!s->stream_adapt || !(s->params.flags & ER_FLAG_STREAM) || s->stream_busy <= 0.0) return;
     const uint32_t lo = s->stream_waves == 12 ? 7u : 10u;
     const uint32_t before = s->stream_tracers;
-    if (s->stream_launch_ms < ER_STREAM_ADAPT_MIN_MS) {
+    // (ER_STREAM_FORCE_BUSY: test knob -- the reading the mechanism is driven with instead of the measured one, whatever the launch's length;
+    // the occupancy itself depends on clocks and may not be asserted on)
+    // (a comma-separated list gives the k-th reading of the render its k-th value, the last one from then on)
+    const char* forced = getenv("ER_STREAM_FORCE_BUSY");
+    double busy = s->stream_busy;
+    if (forced) {
+        const char* q = forced;
+        for (uint32_t k = 0; k < s->stream_readings; k++) { const char* c = strchr(q, ','); if (!c) break; q = c + 1; }
+        busy = atof(q);
+    }
+    s->stream_readings++;
+    if (!forced && s->stream_launch_ms < ER_STREAM_ADAPT_MIN_MS) {
         if (verbose) fprintf(stderr, "[er_stream] tracer lanes %.3f full in a launch of %.2f ms: too short to be a reading\n", s->stream_busy, s->stream_launch_ms);
         return;
     }
-    if (s->stream_busy < 0.85) {
+    if (busy < 0.85) {
         if (++s->stream_low_streak >= 2u && s->stream_tracers > lo) { s->stream_tracers--; s->stream_low_streak = 0; }
     } else {
         s->stream_low_streak = 0;
-        if (s->stream_busy > 0.93 && s->stream_up_budget > 0u && s->stream_tracers < s->stream_tracers_start) { s->stream_tracers++; s->stream_up_budget--; }
+        if (busy > 0.93 && s->stream_up_budget > 0u && s->stream_tracers < s->stream_tracers_start) { s->stream_tracers++; s->stream_up_budget--; }
     }
-    if (verbose) fprintf(stderr, "[er_stream] tracer lanes %.3f full at %u + %u waves -> %u + %u\n", s->stream_busy, before, s->stream_waves - before, s->stream_tracers, s->stream_waves - s->stream_tracers);
+    if (verbose) fprintf(stderr, "[er_stream] tracer lanes %.3f full%s at %u + %u waves -> %u + %u\n", busy, forced ? " (forced reading)" : "", before, s->stream_waves - before, s->stream_tracers, s->stream_waves - s->stream_tracers);
 }
 
 static int er_wait_impl(ErScene* s, float* elapsed_ms) {

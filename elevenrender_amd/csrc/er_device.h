@@ -95,6 +95,9 @@ struct DevScene {
     const uint32_t* owned_tiles;
     uint32_t owned_tile_count;
     DevCounters* counters;
+    // streaming schedule, while the deal of tiles to the XCDs is undecided (er_api.cpp er_stream_adapt): per tile of the frame, the sum
+    // of the path lengths of its finished samples -- WORK counted by the kernel, the same on every run of the same frame; NULL = do not count
+    uint32_t* tile_cost;
 };
 
 // Where pass `pass` of pixel `idx` lives in DevScene::passes.  The four planes a finished sample is accumulated into -- beauty, normal,

@@ -192,9 +192,13 @@ struct ErScene {
     bool stream_adapt = false;                          //   move a wave between the roles by how full the tracer lanes were (er_stream_adapt)
     double stream_busy = 0.0;                           //   tracer lanes that held a ray, last completed call
     double stream_launch_ms = 0.0;                      //   device time of that call's launch (start stamp to the last XCD's end stamp)
-    uint32_t stream_low_streak = 0, stream_up_budget = 1, stream_tracers_start = 0;   //   er_stream_adapt: consecutive low readings; steps back up left; the split the render began with
+    uint32_t stream_low_streak = 0, stream_up_budget = 1, stream_tracers_start = 0, stream_readings = 0;   //   er_stream_adapt: consecutive low readings; steps back up left; the split the render began with
     uint32_t stream_deal_off = 0, stream_deal_n = 0;    //   the deal in use inside d_deal (entries): the one of large super-tiles first, the default edge's after it
-    uint32_t stream_deal_alt_off = 0, stream_deal_alt_n = 0;   //   the fallback deal (0 entries: none), taken when the XCDs of a call finished too far apart
+    uint32_t stream_deal_alt_off = 0, stream_deal_alt_n = 0;   //   the deal of large screen regions beside it (0 entries: none)
+    bool stream_deal_pending = false;                   //   the first completed call decides between the two (er_stream_adapt), from ...
+    DevBuf<uint32_t> d_tile_cost;                       //   ... DevScene::tile_cost: per tile of the frame, the summed path lengths of its finished samples
+    std::vector<uint32_t> stream_deal_large;            //   host copy of the large deal until then (which XCD gets which tile under it)
+    double stream_cost_spread = -1.0;                   //   (max - min) / mean of the XCDs' counted work under the large deal; < 0: not decided yet
     double stream_xcd_spread = 0.0;                     //   (latest - earliest XCD) / launch duration of the last completed call; < 0: not measured
     uint64_t stream_launches = 0, stream_adapted = 0;   //   launches enqueued / the launch whose measurements er_stream_adapt has already used
     std::vector<WfState> wf;              // slot pools (see er_render_begin)
@@ -228,7 +232,7 @@ struct ErScene {
     void release_device() {
         d_nodes.release(); d_nodes8.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_plane.release(); d_materials.release();
         d_textures.release(); d_tex_pool.release(); d_lights.release(); d_cdf.release(); d_samples.release(); d_rng.release();
-        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_deal.release(); d_ray_log.release(); d_mat_fused.release(); d_mat_pre.release(); d_dev.release();
+        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_deal.release(); d_ray_log.release(); d_mat_fused.release(); d_mat_pre.release(); d_dev.release(); d_tile_cost.release();
         for (auto& kv : d_rank_tiles) kv.second.release();
         d_rank_tiles.clear();
         d_gather_mine.release();

@@ -19,16 +19,17 @@ struct WfState;
 #define ER_STREAM_SUPER_TILE_DEFAULT 8u   // side of the screen regions dealt whole to one XCD, in tiles: the deal that spreads a frame's cost evenly
 #endif
 #ifndef ER_STREAM_SUPER_TILE_LARGE
-#define ER_STREAM_SUPER_TILE_LARGE 16u    // the deal a render STARTS with: an XCD's 512 tiles in flight are two compact regions instead of eight, +1.6 % on C2, +5 % on
-                                          // C4, +2.5 % on C5 (frames of even cost) -- and -8 ... -18 % on frames whose cost is uneven (the soup seen from far away / off
-                                          // to one side: fewer, larger regions per XCD sample the cost too coarsely), so the library keeps it only while the XCDs of a
-                                          // call finish within ER_STREAM_XCD_SPREAD_MAX of each other (er_api.cpp er_stream_adapt; profiles/r04_sweep_super_tile.log)
+#define ER_STREAM_SUPER_TILE_LARGE 16u    // the deal a render moves to after its first call if the frame's cost is even: an XCD's 512 tiles in flight are two compact regions
+                                          // instead of eight, +1.6 % on C2, +5 % on C4, +2.5 % on C5 (frames of even cost) -- and -8 ... -18 % on frames whose cost is uneven
+                                          // (the soup seen from far away / off to one side: fewer, larger regions per XCD sample the cost too coarsely), so the library
+                                          // takes it only if the XCDs' shares of the work COUNTED during the first call (path lengths per tile) are within
+                                          // ER_STREAM_COST_SPREAD_MAX of each other under it (er_api.cpp er_stream_adapt; profiles/r04_sweep_super_tile.log, r05_deal_by_counted_work.log)
+#endif
+#ifndef ER_STREAM_COST_SPREAD_MAX
+#define ER_STREAM_COST_SPREAD_MAX 0.04    // (max - min) / mean of the eight XCDs' summed path lengths under the large deal: 0.011 C4, 0.019 Cornell at 1080p, 0.021 C2 (large regions +0.6 ... +4 %); 0.125 / 0.40 on the soup off to one side / from far away (large regions -8 % / -18 %)
 #endif
 #ifndef ER_STREAM_ADAPT_MIN_MS
 #define ER_STREAM_ADAPT_MIN_MS 4.0       // a launch shorter than this (device time) is no reading of the tracer lanes' occupancy: start-up and tail dominate it
-#endif
-#ifndef ER_STREAM_XCD_SPREAD_MAX
-#define ER_STREAM_XCD_SPREAD_MAX 0.10     // (measured: 0.02 ... 0.09 on every deal of every frame tried -- the XCDs never finish together -- 0.15 and 0.32 on large regions of uneven cost)
 #endif
 #ifndef ER_STREAM_SMALL_SHARE
 #define ER_STREAM_SMALL_SHARE 1152u  // owned pixels per CU up to which a workgroup runs as 12 waves of 168 registers (9 tracers + 3 shaders) instead of 16 of 128

@@ -691,12 +691,15 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 const float4 L4 = W.light(slot);
                 F3 light = f3(L4.x, L4.y, L4.z);
                 rs = __builtin_bit_cast(uint32_t, L4.w);
+                const float4 R4 = W.reduc(slot);
+                const uint32_t packed = __builtin_bit_cast(uint32_t, R4.w);
+                // while the host has not yet decided which deal of tiles the frame gets, the path's length goes to its tile's sum (a count of
+                // work, not a time: the decision is the same on every run of the same frame; one fire-and-forget atomic per finished sample)
+                if (S.tile_cost) __hip_atomic_fetch_add(&S.tile_cost[(pxy >> 19) * S.tiles_x + ((pxy & 0xFFFFu) >> 3)], (packed & 0xFFFFu) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((e >> ST_SLOT_BITS) != 0) {
                     // straight from the tracers: the path's last ray left the scene.  What the shading step does for such a slot --
                     // the previous bounce's shadow verdicts (certain ones: the tracers checked), then the miss branch of the bounce.
-                    const float4 R4 = W.reduc(slot);
                     F3 reduction = f3(R4.x, R4.y, R4.z);
-                    const uint32_t packed = __builtin_bit_cast(uint32_t, R4.w);
                     uint32_t bounce = packed & 0xFFFFu;
                     if (packed & WF_PENDING_BIT) {
                         const float4 c = W.occluded(slot) ? W.c_occ(slot) : W.c_vis(slot);

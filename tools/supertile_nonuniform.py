@@ -23,8 +23,10 @@ def ms_per_pass(sc, max_bounces, spp=16):
 
 
 def main():
-    edges = [int(a) for a in sys.argv[1:]] or [8, 16]
+    edges = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()] or [8, 16, 0]      # 0 = the library's own choice (counted work of the first call)
+    os.environ["ER_STREAM_VERBOSE"] = "1"      # the "[er_stream] counted work ..." line of the automatic choice goes to stderr
     cases = []
+    cases.append(("C2 as benched (the soup fills the frame)", scenes.soup(1_000_000, 1920, 1080, seed=12345), 8))
     sc = scenes.soup(1_000_000, 1920, 1080, seed=12345)
     sc.camera.position = abi.ErVec3(0.01, 0.02, -3.0)
     sc._desc = None
@@ -34,6 +36,8 @@ def main():
     sc._desc = None
     cases.append(("soup off to one side", sc, 8))
     cases.append(("C1 Cornell box at 1920x1080", scenes.cornell(1920, 1080), 5))
+    if "--c4" in sys.argv:
+        cases.append(("C4 (10 M triangles, 4K)", scenes.blob_instances(), 8))
     for name, sc, mb in cases:
         for e in edges:
             if e > 0:
