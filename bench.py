@@ -216,7 +216,8 @@ def main():
     ap.add_argument("--no-trace-phase", action="store_true", help="skip the single-pool pass that measures the traversal phase alone")
     ap.add_argument("--per-step-launch", action="store_true", help="one launch per step instead of one launch for all K steps")
     ap.add_argument("--schedule", choices=["auto", "wavefront", "fused", "megakernel", "stream"], default="auto")
-    ap.add_argument("--gpu-build", action="store_true", help="build the BVH on the GPU (ER_FLAG_GPU_BUILD) instead of the host SAH build")
+    ap.add_argument("--gpu-build", action="store_true", help="force the device BVH build (ER_FLAG_GPU_BUILD; the default for scenes of >= 20 000 triangles since round 5)")
+    ap.add_argument("--host-build", action="store_true", help="force the host BVH build (ER_FLAG_HOST_BUILD)")
     ap.add_argument("--sim-world", type=int, default=0, help="(diagnostic) render only rank --sim-rank's tiles of this many, no collective")
     ap.add_argument("--sim-rank", type=int, default=0)
     ap.add_argument("--no-projection", action="store_true", help="skip the `projected` block (N = 1 only): rank 0's share of a 2-, 4- and 8-way tile split rendered alone on this GPU")
@@ -261,7 +262,7 @@ def main():
     scene, ext_flags, workload = make_scene(args, scenes, abi)
     shard_rank, shard_world = (args.sim_rank, args.sim_world) if (args.sim_world > 1 and world == 1) else (rank, world)
     sched_flag = {"auto": 0, "wavefront": abi.FLAG_WAVEFRONT, "fused": abi.FLAG_FUSED, "megakernel": abi.FLAG_MEGAKERNEL, "stream": abi.FLAG_STREAM}[args.schedule]
-    base_flags = sched_flag | ext_flags | (abi.FLAG_GPU_BUILD if args.gpu_build else 0)
+    base_flags = sched_flag | ext_flags | (abi.FLAG_GPU_BUILD if args.gpu_build else 0) | (abi.FLAG_HOST_BUILD if args.host_build else 0)
 
     def manager(extra_flags):
         rm_ = render.RenderingManager(render.RenderParameters(sampleTarget=CONFIGS[args.config][2], max_bounces=max_bounces, device=f"hip:{local_rank}",
@@ -338,7 +339,7 @@ def main():
         schedule_fallback = region["error"] or "another rank failed"
         if region.get("rm") is not None:
             region["rm"].close()
-        base_flags = abi.FLAG_WAVEFRONT | ext_flags | (abi.FLAG_GPU_BUILD if args.gpu_build else 0)
+        base_flags = abi.FLAG_WAVEFRONT | ext_flags | (abi.FLAG_GPU_BUILD if args.gpu_build else 0) | (abi.FLAG_HOST_BUILD if args.host_build else 0)
         sched_flag = abi.FLAG_WAVEFRONT
         region = timed_region()
     if not region["ok_all"]:
@@ -481,7 +482,7 @@ def main():
         traffic_source = None
         # HBM-side bytes from rocprofv3 PMC passes of THIS command line (tools/pmc_passes.sh + tools/pmc_traffic.py; counters cannot be
         # collected inside a timed run): replayed, and only for the exact workload they were recorded on
-        standard = args.tris == 1_000_000 and not (args.width or args.height) and not args.max_bounces and not args.gpu_build and world == 1 and shard_world == 1
+        standard = args.tris == 1_000_000 and not (args.width or args.height) and not args.max_bounces and world == 1 and shard_world == 1
         cfg_key = args.config + ("_nolights" if args.config == "C5" and args.no_lights else "")
         if sched == "stream" and standard:
             for tag in (PROFILE_TAG, "r03"):
@@ -556,7 +557,7 @@ def main():
                              "node": round(ci["trace_node_lanes"] / (64.0 * ci["trace_wave_steps"]), 4),
                              "tri": round(ci["trace_tri_lanes"] / (64.0 * ci["trace_wave_steps"]), 4)}},
             "accel": {"nodes": accel["node_count"], "node_bytes": accel["node_bytes"], "leaves": accel["leaf_count"],
-                      "max_depth": accel["max_depth"], "build_ms": round(accel["build_ms"], 1), "builder": "device linear BVH" if accel["builder"] else "host binned SAH", "upload_ms": round(accel["upload_ms"], 2)},
+                      "max_depth": accel["max_depth"], "build_ms": round(accel["build_ms"], 1), "builder": "device binned SAH" if accel["builder"] else "host binned SAH", "upload_ms": round(accel["upload_ms"], 2)},
             # every repeat of the timed region (each exactly `steps` steps between two barriers): `value` is the median one
             "repeats": {"k": K, "values": [round(v, 3) for v in rep_values], "median_index": mid, "min": round(min(rep_values), 3), "max": round(max(rep_values), 3),
                         "spread": round((max(rep_values) - min(rep_values)) / max(rep_values[mid], 1e-12), 5),

@@ -19,6 +19,7 @@ ER_ERR_INVALID_ARG, ER_ERR_NO_DEVICE, ER_ERR_HIP, ER_ERR_STATE, ER_ERR_OOM = -1,
 PASS_BEAUTY, PASS_DENOISE, PASS_NORMAL, PASS_TANGENT, PASS_BITANGENT, PASS_COUNT = 0, 1, 2, 3, 4, 5
 PASS_NAMES = {"beauty": 0, "denoise": 1, "normal": 2, "tangent": 3, "bitangent": 4}
 FLAG_POINT_LIGHTS, FLAG_COUNTERS, FLAG_MEGAKERNEL, FLAG_PROFILE, FLAG_FUSED, FLAG_WAVEFRONT, FLAG_GPU_BUILD, FLAG_MIS, FLAG_STREAM = 1, 2, 4, 8, 16, 32, 64, 128, 256
+FLAG_HOST_BUILD = 512
 
 
 class ErVec3(C.Structure):

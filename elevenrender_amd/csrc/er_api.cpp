@@ -189,13 +189,21 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             return fail(ER_ERR_HIP, std::string("er_render_begin: libeleven_hip.so has no usable gfx950 code object for ") + (which ? which : "?") +
                                         " on this device (" + hipGetErrorString(pe) + "); rebuild with `make -C elevenrender_amd/csrc`");
     }
-    if (((p->flags & ER_FLAG_GPU_BUILD) || getenv("ER_GPU_BUILD")) && s->tri_count > ER_BVH_LEAF_MAX) {
-        // whole structure on the device (er_gpu_build.hip): tree, wide-node collapse, slot order, triangle records
+    // Which builder: the device build (er_gpu_build.hip: the host builder's binned SAH, level by level on the GPU -- the same tree in a
+    // fraction of the time) unless the scene is small enough for the host to be done before the device has started, or the caller says so.
+    const bool force_dev = (p->flags & ER_FLAG_GPU_BUILD) || getenv("ER_GPU_BUILD");
+    const bool force_host = !force_dev && ((p->flags & ER_FLAG_HOST_BUILD) || getenv("ER_HOST_BUILD"));
+    uint32_t min_tris = ER_GPU_BUILD_MIN_TRIS;
+    if (const char* e = getenv("ER_GPU_BUILD_MIN_TRIS")) min_tris = (uint32_t)std::max(0, atoi(e));
+    if (!force_host && (force_dev || s->tri_count >= min_tris) && s->tri_count > ER_BVH_LEAF_MAX) {
+        // whole structure on the device: tree, wide-node collapse, slot order, triangle records
         std::string why;
         ErGpuSceneArrays arrays{s->vertices.data(), s->normals.data(), s->tangents.data(), s->uvs.data(), s->tangent_sign.data(), s->material_id.data()};
         ErGpuBvhDevice g;
         int brc = er_gpu_build_device(arrays, s->tri_count, s->device, &g, why);
-        if (brc < 0) return fail(ER_ERR_HIP, "er_render_begin: device BVH build: " + why);
+        if (brc < 0 && force_dev) return fail(ER_ERR_HIP, "er_render_begin: device BVH build: " + why);
+        if (brc != 0 && getenv("ER_GPU_BUILD_VERBOSE")) fprintf(stderr, "[er_gpu_build] %s: the host builds instead\n", why.c_str());
+        if (brc < 0) (void)hipGetLastError();      // (a failed default build -- device memory, say -- is not the call's failure: the host builder takes over)
         if (brc == 0) {
             // the scene owns the three buffers from here on (release_device frees them on any later error)
             s->d_nodes.release(); s->d_nodes8.release(); s->d_attr.release();
@@ -209,7 +217,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             lift_bound = g.lift_bound;
             build_ms = g.build_ms;
             built = true;
-        }   // brc > 0: the device builder declined (tree too deep for the traversal stacks): host build
+        }   // brc > 0: the device builder declined (tree too deep for the traversal stacks); brc < 0 without the flag: it failed -- host build
     }
     if (built) HIP_TRY(hipEventRecord(u0, s->stream));
     if (!built) {
@@ -564,7 +572,9 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         s->shade_blocks = cus * 5;
         if (const char* e = getenv("ER_TRACE_WAVES_PER_CU")) s->trace_blocks = cus * (uint32_t)std::max(1, atoi(e));   // tuning knob
         if (const char* e = getenv("ER_SHADE_WAVES_PER_CU")) s->shade_blocks = cus * (uint32_t)std::max(1, atoi(e));
-        const size_t spill_per_pool = (size_t)s->trace_blocks * ER_BVH_MAX_DEPTH * 64;
+        // (uint2 entries: the trace waves' stack levels beyond the LDS ones, then the shade waves' exact re-trace stacks, two ints per entry)
+        const size_t trace_spill = (size_t)s->trace_blocks * ER_BVH_MAX_DEPTH * 64;
+        const size_t spill_per_pool = trace_spill + (size_t)s->shade_blocks * ER_BVH_MAX_DEPTH * 32;
         if ((rc = upload(s->d_spill, nullptr, spill_per_pool * pools, s->stream)) != ER_OK) return rc;
         s->wf.clear();
         for (uint32_t p2 = 0; p2 < pools; p2++) {
@@ -573,6 +583,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             W.q[0] = q; W.q[1] = q + qcap; W.qs[0] = q + 2 * qcap; W.qs[1] = q + 2 * qcap + qs_cap;
             W.counts = cbase + (size_t)p2 * WF_COUNTS;
             W.spill = s->d_spill.p + (size_t)p2 * spill_per_pool;
+            W.shade_stack = (int*)(W.spill + trace_spill);
             s->wf.push_back(W);
         }
         for (uint32_t p2 = 1; p2 < pools; p2++) {

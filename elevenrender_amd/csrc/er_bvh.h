@@ -15,7 +15,7 @@
 #include <stdint.h>
 #include <vector>
 
-#define ER_BVH_MAX_DEPTH 32   // also the LDS stack depth per lane
+#define ER_BVH_MAX_DEPTH 64   // also the stack depth per lane of the binary-tree routines (32 until round 5: the device builder's trees of 10 M triangles are deeper)
 #ifndef ER_BVH_LEAF_MAX
 #define ER_BVH_LEAF_MAX 2   // measured on C2: 2 -> 838, 3 -> 792, 4 -> 764 Msamples/s (fewer triangle fetches per ray)
 #endif

@@ -6,6 +6,10 @@
 
 #include "er_bvh.h"
 
+#ifndef ER_GPU_BUILD_MIN_TRIS
+#define ER_GPU_BUILD_MIN_TRIS 20000u   // scenes of fewer triangles take the host build by default (a few ms there; the device build is a few ms of launches whatever the size)
+#endif
+
 // Whole structure on the device: binary tree, SAH-optimal collapse into 8-wide nodes, final slot order and the
 // triangle records, in the buffers er_render_begin hands to the kernels.  Nothing but a few counters comes back.
 // Returns 0 on success; > 0 = the device builder declines (too few triangles, tree deeper than the traversal stack

@@ -1,38 +1,35 @@
-// er_gpu_build.hip -- device-side builder of the binary BVH.
+// er_gpu_build.hip -- device-side builder of the acceleration structure.
 //
 // The reference builds its tree on the host, one node at a time (reference src/BVH.cpp:132-415, 11.7 s for
-// 1M triangles); the contract is only "same nearest hit", so the tree is free to differ.  The default builder of
-// this library is the host binned-SAH build (er_bvh.cpp, 0.25 s + 0.2 s collapse at 1M on 16 threads); this file
-// is the fast alternative (ER_FLAG_GPU_BUILD): the whole structure built on the GPU --
+// 1M triangles); the contract is only "same nearest hit", so the tree is free to differ.  This file builds the whole
+// structure on the GPU and is the library's default builder since round 5 (er_api.cpp: scenes of at least
+// ER_GPU_BUILD_MIN_TRIS triangles; ER_FLAG_HOST_BUILD keeps the host build of er_bvh.cpp, which is also what a declined or
+// failed device build falls back to):
 //
-//   1. bounds      per-triangle padded box, centroid, lift bound (the same arithmetic as er_build_bvh); the
-//                  centroid bounds of the scene by a wave reduction + one atomic pair per wave;
-//   2. morton      63-bit Morton code of the centroid (21 bits per axis);
-//   3. sort        rocPRIM radix sort of (code, triangle) pairs -- the only library call;
-//   4. tree        Karras 2012: every inner node finds its key range and split by binary search on the length of
-//                  the common prefix (ties broken by the position, so equal codes still make a finite tree);
-//   5. refit       leaves walk up; the second child to arrive at a node (an atomic counter decides) unites the
-//                  two boxes and goes on; heights ride along, so the depth bound of the traversal stacks can be
-//                  checked (a tree deeper than ER_BVH_MAX_DEPTH - 1 makes the caller fall back to the host build);
-//   6. pair        an inner node whose two children are single triangles becomes a two-triangle leaf of its
-//                  parent (leaves of this library hold <= 2 triangles, neighbours in slot order).
-//
-//   7. collapse    the SAH-optimal collapse into 8-wide compressed nodes (the dynamic programme and the breadth-first
-//                  layout of er_collapse_bvh8, er_bvh.cpp): the DP bottom-up with the same last-arrival rule as
-//                  the refit, the emission one tree level per launch with prefix sums for the node and triangle
-//                  positions, so the layout never depends on thread timing;
-//   8. records     the binary tree's leaf references follow the new slot order; the 48-byte intersection and
+//   1. bounds      per-triangle padded box and lift bound (the same arithmetic as er_build_bvh), largest coordinate;
+//   2. binary tree top-down binned SAH, the host builder's algorithm, one tree level per round (comment above k_sah_cen);
+//   3. collapse    the SAH-optimal collapse into 8-wide compressed nodes (the dynamic programme and the breadth-first
+//                  layout of er_collapse_bvh8, er_bvh.cpp): the DP bottom-up with a last-arrival rule, the emission one
+//                  tree level per launch with prefix sums for the node and triangle positions, so the layout never
+//                  depends on thread timing;
+//   4. records     the binary tree's leaf references follow the new slot order; the 48-byte intersection and
 //                  112-byte attribute records are written in that order straight from the scene arrays.
 //
-// Everything the kernels read is produced in place on the device; a few counters come back.  Measured on MI355X:
-// 1M triangles 60 ms against 451 ms for the host build (er_bvh.cpp, 16 threads), 9.68M triangles 242 ms against
-// 5.1 s.  A linear BVH is a slightly worse tree than the binned-SAH build -- 21.7 instead of 20.7 node visits per
-// ray on the 1M soup, 950 instead of 961 Msamples/s -- which is why it is the option and not the default.  Every
-// image is identical bit for bit whichever builder made the tree (tests/test_gpu_build.py).
+// Everything the kernels read is produced in place on the device; a few counters come back.  Measured on MI355X (round 5,
+// profiles/r05_ab_device_sah_builder.log): 1M triangles 65-73 ms against 420-435 ms for the host build (16 threads) and 9 ms
+// instead of 112 ms of upload; 10M triangles 325-340 ms against 5.0-5.2 s (+ 17 ms instead of 830 ms) -- and the SAME tree:
+// 119 146 wide nodes and 20.67 node visits per ray on C2, 1 169 040 and 18.43 on C4, the same Msamples/s.  Round 1's builder
+// here was a radix tree over Morton codes (Karras 2012): 5 % more node visits per ray, 2.5 % slower frames, and too deep for
+// the traversal stacks on the 10 M-triangle scene, where it silently declined; a locally-ordered clustering (Meister and
+// Bittner 2018) tried in round 5 made a worse wide tree still (profiles/r05_ab_builder_ploc.log).  Every image is identical
+// bit for bit whichever builder made the tree (tests/test_gpu_build.py).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>     // (before rocprim: its texture iterator calls the host memset)
 #include <string>
 #include <vector>
@@ -54,53 +51,33 @@ __device__ __forceinline__ float ord2f(unsigned u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
-// pass 1: largest |coordinate| (absolute box pad) and the bounds of the centroids (Morton grid)
-__global__ __launch_bounds__(256) void k_scene_bounds(const float* __restrict__ v, uint32_t n, unsigned* g /* [0] vmax bits, [1..3] lo, [4..6] hi */) {
+// pass 1: largest |coordinate| (the absolute part of the box padding, as er_build_bvh)
+__global__ __launch_bounds__(256) void k_scene_bounds(const float* __restrict__ v, uint32_t n, unsigned* g /* [0] vmax bits */) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    float vm = 0, c[3] = {INFINITY, INFINITY, INFINITY}, d[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float vm = 0;
     if (i < n) {
         const float* p = v + (size_t)i * 9;
         for (int k = 0; k < 9; k++) vm = fmaxf(vm, fabsf(p[k]));
-        for (int a = 0; a < 3; a++) c[a] = d[a] = (p[a] + p[3 + a] + p[6 + a]) * (1.0f / 3.0f);
     }
-    for (int off = 32; off >= 1; off >>= 1) {
-        vm = fmaxf(vm, __shfl_xor(vm, off, 64));
-        for (int a = 0; a < 3; a++) { c[a] = fminf(c[a], __shfl_xor(c[a], off, 64)); d[a] = fmaxf(d[a], __shfl_xor(d[a], off, 64)); }
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicMax(&g[0], __float_as_uint(vm));     // vm >= 0: the bit pattern orders like the value
-        for (int a = 0; a < 3; a++) { atomicMin(&g[1 + a], f2ord(c[a])); atomicMax(&g[4 + a], f2ord(d[a])); }
-    }
+    for (int off = 32; off >= 1; off >>= 1) vm = fmaxf(vm, __shfl_xor(vm, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&g[0], __float_as_uint(vm));     // vm >= 0: the bit pattern orders like the value
 }
 
-__device__ __forceinline__ unsigned long long spread21(unsigned x) {   // 21 bits -> every third bit of 63
-    unsigned long long v = x & 0x1fffffu;
-    v = (v | (v << 32)) & 0x1f00000000ffffull;
-    v = (v | (v << 16)) & 0x1f0000ff0000ffull;
-    v = (v | (v << 8)) & 0x100f00f00f00f00full;
-    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
-    v = (v | (v << 2)) & 0x1249249249249249ull;
-    return v;
-}
-
-// pass 2: padded box, lift bound (er_build_bvh's arithmetic, reference src/Tri.h:106-112), Morton code
+// pass 2: padded box, lift bound (er_build_bvh's arithmetic, reference src/Tri.h:106-112)
 __global__ __launch_bounds__(256) void k_prims(const float* __restrict__ v, const float* __restrict__ nrm, uint32_t n, const unsigned* __restrict__ g,
-                                                Box3* __restrict__ boxes, float* __restrict__ lift, unsigned long long* __restrict__ keys,
-                                                uint32_t* __restrict__ ids, unsigned* __restrict__ lift_max) {
+                                                Box3* __restrict__ boxes, float* __restrict__ lift, unsigned* __restrict__ lift_max) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     float my_lift = 0;
     if (i < n) {
         const float pad_abs = __uint_as_float(g[0]) * 1e-6f;
         const float* p = v + (size_t)i * 9;
         Box3 b;
-        float c[3];
         for (int a = 0; a < 3; a++) {
             float lo = fminf(fminf(p[a], p[3 + a]), p[6 + a]), hi = fmaxf(fmaxf(p[a], p[3 + a]), p[6 + a]);
             float m = fmaxf(fabsf(lo), fabsf(hi));
             float pad = fmaxf(m * 4e-7f + 1e-37f, pad_abs);
             b.lo[a] = lo - pad;
             b.hi[a] = hi + pad;
-            c[a] = (p[a] + p[3 + a] + p[6 + a]) * (1.0f / 3.0f);
         }
         boxes[i] = b;
         const float* nn = nrm + (size_t)i * 9;
@@ -117,123 +94,286 @@ __global__ __launch_bounds__(256) void k_prims(const float* __restrict__ v, cons
         }
         lift[i] = (float)(tl * 1.01) + 1e-30f;
         my_lift = (float)(tl * 1.01);
-        unsigned q[3];
-        for (int a = 0; a < 3; a++) {
-            float lo = ord2f(g[1 + a]), hi = ord2f(g[4 + a]);
-            float t = hi > lo ? (c[a] - lo) / (hi - lo) : 0.0f;
-            t = fminf(fmaxf(t, 0.0f), 1.0f);
-            q[a] = (unsigned)fminf(t * 2097152.0f, 2097151.0f);
-        }
-        keys[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
-        ids[i] = i;
     }
     for (int off = 32; off >= 1; off >>= 1) my_lift = fmaxf(my_lift, __shfl_xor(my_lift, off, 64));
     if ((threadIdx.x & 63) == 0) atomicMax(lift_max, __float_as_uint(my_lift));
 }
 
-// length of the common prefix of the keys at sorted positions i and j (position bits break ties); -1 outside
-__device__ __forceinline__ int delta(const unsigned long long* __restrict__ keys, uint32_t n, int i, int j) {
-    if (j < 0 || j >= (int)n) return -1;
-    const unsigned long long a = keys[i], b = keys[j];
-    if (a != b) return __clzll((long long)(a ^ b));
-    return 64 + __clz(i ^ j);
+// ---------------------------------------------------------------------------------------------------------
+// Round 5: the host builder's own algorithm on the device -- top-down binned SAH (er_bvh.cpp: 16 bins per axis over the
+// centroid bounds, cost = area x count on either side, leaves of <= ER_BVH_LEAF_MAX triangles), one tree LEVEL per round:
+//   k_sah_cb        centroid bounds of every active node (atomic min / max on order-preserving integers);
+//   k_sah_bin       every triangle of an active node into its bin on each axis: count + box (per-wave LDS bins when the
+//                   whole wave works on one node -- the top levels --, global atomics otherwise);
+//   k_sah_split     one thread per active node sweeps the 3 x 15 candidate planes exactly as Builder::split does and
+//                   writes the node: child boxes, the plane, the size of the left side;
+//   (scan)          which children are inner nodes -> their indices in the next round and their node ids (breadth-first);
+//   k_sah_children  child references (inner id or leaf range), parent links, the next round's node list;
+//   k_sah_flags + (scan) + k_sah_scatter   stable partition of every active node's triangles by its plane.
+// The triangles of a subtree are consecutive slots by construction, two-triangle leaves come out directly (no pairing
+// pass), the root is node 0, the depth is that of the host build (26 at 1 M triangles, ~30 at 10 M) and bounded by the same
+// guard, and the tree is of the host build's quality because it is the host build's tree up to float rounding of the bins.
+// The radix tree over Morton codes of round 1 and a locally-ordered clustering (profiles/r05_ab_builder_ploc.log, r05_ab_device_sah_builder.log)
+// make trees that a ray visits 5 % / 20 % more nodes of.
+// ---------------------------------------------------------------------------------------------------------
+#define SAH_BINS 16
+#define SAH_BIN_WORDS 7                                   // count, lo[3], hi[3] (order-preserving integers)
+#define SAH_NODE_WORDS (3 * SAH_BINS * SAH_BIN_WORDS)     // 336 words = 1 344 bytes of bins per active node
+
+struct SahAct { uint32_t node, lo, hi, depth; float blo[3], bhi[3]; };      // an active node: its id, triangle range, depth and box
+struct SahSplit { int axis, bin; uint32_t left; uint32_t in0, in1; };        // the plane (axis < 0: by position), the left side's size, which children are inner
+
+__device__ __forceinline__ int sah_bin_of(float c, float lo, float ext) {
+    const float scale = (float)SAH_BINS / ext;
+    int b = (int)((c - lo) * scale);
+    return b < 0 ? 0 : (b >= SAH_BINS ? SAH_BINS - 1 : b);
 }
 
-// Karras 2012, "Maximizing parallelism in the construction of BVHs, octrees, and k-d trees", section 4
-__global__ __launch_bounds__(256) void k_tree(const unsigned long long* __restrict__ keys, uint32_t n, int2* __restrict__ children,
-                                               int* __restrict__ parent_inner, int* __restrict__ parent_leaf) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int)n - 1) return;
-    const int d = delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1) >= 0 ? 1 : -1;
-    const int dmin = delta(keys, n, i, i - d);
-    int lmax = 2;
-    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
-    int l = 0;
-    for (int t = lmax / 2; t >= 1; t /= 2)
-        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
-    const int j = i + l * d;
-    const int dnode = delta(keys, n, i, j);
-    int s = 0;
-    for (int t = (l + 1) / 2, prev = l; prev > 1; prev = t, t = (t + 1) / 2)
-        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
-    const int gamma = i + s * d + (d < 0 ? -1 : 0);
-    const int lo = i < j ? i : j, hi = i < j ? j : i;
-    // child reference: >= 0 inner node; < 0 leaf ~((slot << 3) | 0)
-    const int c0 = lo == gamma ? ~(gamma << 3) : gamma;
-    const int c1 = hi == gamma + 1 ? ~((gamma + 1) << 3) : gamma + 1;
-    children[i] = make_int2(c0, c1);
-    if (c0 < 0) parent_leaf[gamma] = i * 2; else parent_inner[gamma] = i * 2;
-    if (c1 < 0) parent_leaf[gamma + 1] = i * 2 + 1; else parent_inner[gamma + 1] = i * 2 + 1;
+__global__ __launch_bounds__(256) void k_sah_cen(const float* __restrict__ v, uint32_t n, float* __restrict__ cen) {      // the host builder's centroid
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* p = v + (size_t)i * 9;
+    for (int a = 0; a < 3; a++) cen[(size_t)i * 3 + a] = (p[a] + p[3 + a] + p[6 + a]) * (1.0f / 3.0f);
 }
 
-// refit: one thread per leaf walks up; the second arrival at a node owns it
-__global__ __launch_bounds__(256) void k_refit(const Box3* __restrict__ boxes, const uint32_t* __restrict__ ids, uint32_t n, const int2* __restrict__ children,
-                                                const int* __restrict__ parent_inner, const int* __restrict__ parent_leaf, ErNode* nodes,
-                                                unsigned* visits, unsigned* heights, unsigned* max_height) {
-    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    Box3 b = boxes[ids[j]];
-    int link = parent_leaf[j];
-    unsigned h = 0;
-    while (true) {
-        const int p = link >> 1, side = link & 1;
-        ErNode* nd = nodes + p;
-        float* lo = side ? nd->lo1 : nd->lo0;
-        float* hi = side ? nd->hi1 : nd->hi0;
-        for (int a = 0; a < 3; a++) { lo[a] = b.lo[a]; hi[a] = b.hi[a]; }
-        atomicMax(&heights[p], h + 1);
-        __threadfence();
-        if (atomicAdd(&visits[p], 1u) == 0) return;      // the sibling subtree is not finished: it will carry on
-        __threadfence();
-        const volatile float* l0 = nd->lo0; const volatile float* h0 = nd->hi0;
-        const volatile float* l1 = nd->lo1; const volatile float* h1 = nd->hi1;
-        for (int a = 0; a < 3; a++) { b.lo[a] = fminf(l0[a], l1[a]); b.hi[a] = fmaxf(h0[a], h1[a]); }
-        h = atomicMax(&heights[p], 0u);                  // both children have reported: this is the node's height
-        const int2 c = children[p];
-        nd->c0 = c.x; nd->c1 = c.y; nd->pad[0] = 0; nd->pad[1] = 0;
-        if (p == 0) { atomicMax(max_height, h); return; }
-        link = parent_inner[p];
+__global__ __launch_bounds__(256) void k_sah_init(uint32_t n, uint32_t* __restrict__ idx, int* __restrict__ node_of) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p < n) { idx[p] = p; node_of[p] = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_sah_clear(unsigned* __restrict__ cbv, uint32_t n_act, unsigned* __restrict__ bins, uint32_t bin_nodes) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (size_t)n_act * 6) cbv[i] = (i % 6) < 3 ? 0xffffffffu : 0u;
+    if (i < (size_t)bin_nodes * SAH_NODE_WORDS) { const uint32_t w = (uint32_t)(i % SAH_BIN_WORDS); bins[i] = w == 0 ? 0u : (w < 4 ? 0xffffffffu : 0u); }
+}
+
+__global__ __launch_bounds__(256) void k_sah_cb(uint32_t n, const uint32_t* __restrict__ idx, const int* __restrict__ node_of, const float* __restrict__ cen,
+                                                 unsigned* __restrict__ cbv) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    const int a = p < n ? node_of[p] : -1;
+    float c[3] = {0, 0, 0};
+    if (a >= 0) { const float* q = cen + (size_t)idx[p] * 3; c[0] = q[0]; c[1] = q[1]; c[2] = q[2]; }
+    const int a0 = __builtin_amdgcn_readfirstlane(a);
+    if (__all(a == a0)) {      // the whole wave in one node (the top levels): one set of atomics per wave
+        if (a0 < 0) return;
+        float lo[3] = {c[0], c[1], c[2]}, hi[3] = {c[0], c[1], c[2]};
+        for (int off = 32; off >= 1; off >>= 1)
+            for (int k = 0; k < 3; k++) { lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64)); hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64)); }
+        if ((threadIdx.x & 63) == 0)
+            for (int k = 0; k < 3; k++) { atomicMin(&cbv[(size_t)a0 * 6 + k], f2ord(lo[k])); atomicMax(&cbv[(size_t)a0 * 6 + 3 + k], f2ord(hi[k])); }
+        return;
+    }
+    if (a < 0) return;
+    for (int k = 0; k < 3; k++) { atomicMin(&cbv[(size_t)a * 6 + k], f2ord(c[k])); atomicMax(&cbv[(size_t)a * 6 + 3 + k], f2ord(c[k])); }
+}
+
+// bins of the active nodes [a_lo, a_hi) (a round whose nodes outnumber the bin buffer runs in several such chunks)
+__global__ __launch_bounds__(256) void k_sah_bin(uint32_t n, const uint32_t* __restrict__ idx, const int* __restrict__ node_of, const float* __restrict__ cen,
+                                                  const Box3* __restrict__ boxes, const unsigned* __restrict__ cbv, unsigned* __restrict__ bins, int a_lo, int a_hi) {
+    __shared__ unsigned s_bins[4][SAH_NODE_WORDS];
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    int a = p < n ? node_of[p] : -1;
+    if (a < a_lo || a >= a_hi) a = -1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int a0 = __builtin_amdgcn_readfirstlane(a);
+    const bool uni = __all(a == a0);
+    if (uni && a0 < 0) return;
+    int b[3] = {-1, -1, -1};
+    Box3 bx;
+    if (a >= 0) {
+        const uint32_t id = idx[p];
+        bx = boxes[id];
+        const float* q = cen + (size_t)id * 3;
+        for (int k = 0; k < 3; k++) {
+            const float lo = ord2f(cbv[(size_t)a * 6 + k]), hi = ord2f(cbv[(size_t)a * 6 + 3 + k]);
+            const float ext = hi - lo;
+            if (ext > 0) b[k] = sah_bin_of(q[k], lo, ext);
+        }
+    }
+    if (uni) {
+        unsigned* sb = s_bins[wave];
+        for (int i = lane; i < SAH_NODE_WORDS; i += 64) { const int w = i % SAH_BIN_WORDS; sb[i] = w == 0 ? 0u : (w < 4 ? 0xffffffffu : 0u); }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int k = 0; k < 3; k++) {
+            if (b[k] < 0) continue;
+            unsigned* t = sb + (k * SAH_BINS + b[k]) * SAH_BIN_WORDS;
+            atomicAdd(&t[0], 1u);
+            for (int m = 0; m < 3; m++) { atomicMin(&t[1 + m], f2ord(bx.lo[m])); atomicMax(&t[4 + m], f2ord(bx.hi[m])); }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned* g = bins + (size_t)(a0 - a_lo) * SAH_NODE_WORDS;
+        for (int i = lane; i < 3 * SAH_BINS; i += 64) {
+            const unsigned* t = sb + i * SAH_BIN_WORDS;
+            if (t[0] == 0u) continue;
+            unsigned* o = g + i * SAH_BIN_WORDS;
+            atomicAdd(&o[0], t[0]);
+            for (int m = 0; m < 3; m++) { atomicMin(&o[1 + m], t[1 + m]); atomicMax(&o[4 + m], t[4 + m]); }
+        }
+        return;
+    }
+    if (a < 0) return;
+    unsigned* g = bins + (size_t)(a - a_lo) * SAH_NODE_WORDS;
+    for (int k = 0; k < 3; k++) {
+        if (b[k] < 0) continue;
+        unsigned* o = g + (k * SAH_BINS + b[k]) * SAH_BIN_WORDS;
+        atomicAdd(&o[0], 1u);
+        for (int m = 0; m < 3; m++) { atomicMin(&o[1 + m], f2ord(bx.lo[m])); atomicMax(&o[4 + m], f2ord(bx.hi[m])); }
     }
 }
 
-// pair: a child that is an inner node over two single triangles becomes a two-triangle leaf
-__global__ __launch_bounds__(256) void k_pair(ErNode* nodes, uint32_t n_inner, unsigned* leaf_count) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ float sah_area(const float* lo, const float* hi) {      // Box::area of er_bvh.cpp
+    const float x = hi[0] - lo[0], y = hi[1] - lo[1], z = hi[2] - lo[2];
+    if (!(x >= 0) || !(y >= 0) || !(z >= 0)) return 0;
+    return 2 * (x * y + x * z + y * z);
+}
+__device__ __forceinline__ int sah_levels_needed(uint32_t n) {      // Builder::levels_needed
+    const uint32_t v = (n + ER_BVH_LEAF_MAX - 1) / ER_BVH_LEAF_MAX;
+    int r = 0;
+    while ((1u << r) < v) r++;
+    return r;
+}
+
+// Builder::split of er_bvh.cpp for the active nodes [a_lo, a_hi), from their bins
+__global__ __launch_bounds__(64) void k_sah_split(const SahAct* __restrict__ act, const unsigned* __restrict__ cbv, const unsigned* __restrict__ bins, int a_lo, int a_hi,
+                                                   SahSplit* __restrict__ split, ErNode* __restrict__ nodes) {
+    const int a = a_lo + (int)(blockIdx.x * 64 + threadIdx.x);
+    if (a >= a_hi) return;
+    const SahAct A = act[a];
+    const uint32_t n = A.hi - A.lo;
+    const unsigned* g = bins + (size_t)(a - a_lo) * SAH_NODE_WORDS;
+    const bool force_median = (int)A.depth + 1 + sah_levels_needed(n) > ER_BVH_MAX_DEPTH - 1;
+    int best_axis = -1, best_bin = -1;
+    float best_cost = INFINITY;
+    for (int axis = 0; axis < 3 && !force_median; axis++) {
+        const float ext = ord2f(cbv[(size_t)a * 6 + 3 + axis]) - ord2f(cbv[(size_t)a * 6 + axis]);
+        if (!(ext > 0)) continue;
+        const unsigned* t = g + axis * SAH_BINS * SAH_BIN_WORDS;
+        float ra[SAH_BINS];
+        uint32_t rc[SAH_BINS];
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t c = 0;
+        for (int b = SAH_BINS - 1; b >= 1; b--) {
+            const unsigned* q = t + b * SAH_BIN_WORDS;
+            if (q[0]) for (int m = 0; m < 3; m++) { lo[m] = fminf(lo[m], ord2f(q[1 + m])); hi[m] = fmaxf(hi[m], ord2f(q[4 + m])); }
+            c += q[0];
+            ra[b] = sah_area(lo, hi);
+            rc[b] = c;
+        }
+        for (int m = 0; m < 3; m++) { lo[m] = INFINITY; hi[m] = -INFINITY; }
+        c = 0;
+        for (int b = 0; b < SAH_BINS - 1; b++) {
+            const unsigned* q = t + b * SAH_BIN_WORDS;
+            if (q[0]) for (int m = 0; m < 3; m++) { lo[m] = fminf(lo[m], ord2f(q[1 + m])); hi[m] = fmaxf(hi[m], ord2f(q[4 + m])); }
+            c += q[0];
+            if (c == 0 || rc[b + 1] == 0) continue;
+            const float cost = sah_area(lo, hi) * (float)c + ra[b + 1] * (float)rc[b + 1];
+            if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+        }
+    }
+    SahSplit S;
+    S.axis = best_axis; S.bin = best_bin;
+    ErNode nd;
+    if (best_axis >= 0) {
+        const unsigned* t = g + best_axis * SAH_BINS * SAH_BIN_WORDS;
+        float l0[3] = {INFINITY, INFINITY, INFINITY}, h0[3] = {-INFINITY, -INFINITY, -INFINITY}, l1[3] = {INFINITY, INFINITY, INFINITY}, h1[3] = {-INFINITY, -INFINITY, -INFINITY};
+        uint32_t c = 0;
+        for (int b = 0; b < SAH_BINS; b++) {
+            const unsigned* q = t + b * SAH_BIN_WORDS;
+            if (!q[0]) continue;
+            if (b <= best_bin) { c += q[0]; for (int m = 0; m < 3; m++) { l0[m] = fminf(l0[m], ord2f(q[1 + m])); h0[m] = fmaxf(h0[m], ord2f(q[4 + m])); } }
+            else for (int m = 0; m < 3; m++) { l1[m] = fminf(l1[m], ord2f(q[1 + m])); h1[m] = fmaxf(h1[m], ord2f(q[4 + m])); }
+        }
+        S.left = c;
+        for (int m = 0; m < 3; m++) { nd.lo0[m] = l0[m]; nd.hi0[m] = h0[m]; nd.lo1[m] = l1[m]; nd.hi1[m] = h1[m]; }
+    } else {
+        // every centroid in one place, or the depth guard: the two halves of the range, each under the node's whole box (rare)
+        S.left = n / 2;
+        for (int m = 0; m < 3; m++) { nd.lo0[m] = A.blo[m]; nd.hi0[m] = A.bhi[m]; nd.lo1[m] = A.blo[m]; nd.hi1[m] = A.bhi[m]; }
+    }
+    S.in0 = S.left > ER_BVH_LEAF_MAX ? 1u : 0u;
+    S.in1 = n - S.left > ER_BVH_LEAF_MAX ? 1u : 0u;
+    nd.c0 = 0; nd.c1 = 0; nd.pad[0] = 0; nd.pad[1] = 0;
+    split[a] = S;
+    nodes[A.node] = nd;
+}
+
+__global__ __launch_bounds__(256) void k_sah_count(const SahSplit* __restrict__ split, uint32_t n_act, uint32_t* __restrict__ kids) {
+    const uint32_t a = blockIdx.x * 256 + threadIdx.x;
+    if (a < n_act) kids[a] = split[a].in0 + split[a].in1;
+}
+
+__global__ __launch_bounds__(256) void k_sah_children(const SahAct* __restrict__ act, const SahSplit* __restrict__ split, const uint32_t* __restrict__ kid_off, uint32_t n_act,
+                                                       uint32_t node_base, ErNode* __restrict__ nodes, int* __restrict__ parent_inner, SahAct* __restrict__ next,
+                                                       int2* __restrict__ child_act, unsigned* __restrict__ totals /* [0] next actives, [1] leaves */) {
+    const uint32_t a = blockIdx.x * 256 + threadIdx.x;
     unsigned leaves = 0;
-    if (i < n_inner) {
-        ErNode* nd = nodes + i;
-        int c[2] = {nd->c0, nd->c1};
-        // (a node over two single triangles is itself absorbed by its parent and must not count its leaves)
-        const bool absorbed_self = i != 0 && c[0] < 0 && c[1] < 0 && ((~c[0]) & 7) == 0 && ((~c[1]) & 7) == 0;
-        for (int k = 0; k < 2 && !absorbed_self; k++) {
-            if (c[k] >= 0) {
-                const int2 cc = make_int2(nodes[c[k]].c0, nodes[c[k]].c1);
-                // (the child still holds its two single-triangle references: only parents rewrite, and only their own fields)
-                if (cc.x < 0 && cc.y < 0 && ((~cc.x) & 7) == 0 && ((~cc.y) & 7) == 0) {
-                    const int first = (~cc.x) >> 3;
-                    c[k] = ~((first << 3) | 1);
-                    leaves++;
-                }
+    if (a < n_act) {
+        const SahAct A = act[a];
+        const SahSplit S = split[a];
+        ErNode* nd = nodes + A.node;
+        const uint32_t off = kid_off[a], cnt = A.hi - A.lo;
+        int ca[2] = {-1, -1};
+        for (int k = 0; k < 2; k++) {
+            const uint32_t lo = k == 0 ? A.lo : A.lo + S.left, hi = k == 0 ? A.lo + S.left : A.hi;
+            const bool inner = k == 0 ? S.in0 != 0 : S.in1 != 0;
+            int ref;
+            if (inner) {
+                const uint32_t na = off + (k == 1 ? S.in0 : 0u);
+                const uint32_t id = node_base + na;
+                ref = (int)id;
+                parent_inner[id] = (int)A.node * 2 + k;
+                SahAct C;
+                C.node = id; C.lo = lo; C.hi = hi; C.depth = A.depth + 1;
+                for (int m = 0; m < 3; m++) { C.blo[m] = k == 0 ? nd->lo0[m] : nd->lo1[m]; C.bhi[m] = k == 0 ? nd->hi0[m] : nd->hi1[m]; }
+                next[na] = C;
+                ca[k] = (int)na;
             } else {
+                ref = ~(int)((lo << 3) | (hi - lo - 1u));
                 leaves++;
             }
+            if (k == 0) nd->c0 = ref; else nd->c1 = ref;
         }
-        nd->pad[0] = c[0];      // staged: written back by k_pair_commit so that no parent reads a rewritten child
-        nd->pad[1] = c[1];
+        child_act[a] = make_int2(ca[0], ca[1]);
+        if (a == n_act - 1) totals[0] = off + S.in0 + S.in1;
+        (void)cnt;
     }
     for (int off = 32; off >= 1; off >>= 1) leaves += __shfl_xor(leaves, off, 64);
-    if ((threadIdx.x & 63) == 0 && leaves) atomicAdd(leaf_count, leaves);
+    if ((threadIdx.x & 63) == 0 && leaves) atomicAdd(&totals[1], leaves);
 }
-__global__ __launch_bounds__(256) void k_pair_commit(ErNode* nodes, uint32_t n_inner, unsigned char* absorbed) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_inner) return;
-    ErNode* nd = nodes + i;
-    const int o0 = nd->c0, o1 = nd->c1;
-    absorbed[i] = (i != 0 && o0 < 0 && o1 < 0 && ((~o0) & 7) == 0 && ((~o1) & 7) == 0) ? 1 : 0;
-    nd->c0 = nd->pad[0];
-    nd->c1 = nd->pad[1];
-    nd->pad[0] = 0;
-    nd->pad[1] = 0;
+
+__global__ __launch_bounds__(256) void k_sah_flags(uint32_t n, const uint32_t* __restrict__ idx, const int* __restrict__ node_of, const float* __restrict__ cen,
+                                                    const SahAct* __restrict__ act, const SahSplit* __restrict__ split, const unsigned* __restrict__ cbv, uint32_t* __restrict__ flag) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int a = node_of[p];
+    uint32_t f = 0;
+    if (a >= 0) {
+        const SahSplit S = split[a];
+        if (S.axis < 0) f = p < act[a].lo + S.left ? 1u : 0u;
+        else {
+            const float lo = ord2f(cbv[(size_t)a * 6 + S.axis]), hi = ord2f(cbv[(size_t)a * 6 + 3 + S.axis]);
+            f = sah_bin_of(cen[(size_t)idx[p] * 3 + S.axis], lo, hi - lo) <= S.bin ? 1u : 0u;
+        }
+    }
+    flag[p] = f;
+}
+
+__global__ __launch_bounds__(256) void k_sah_scatter(uint32_t n, const uint32_t* __restrict__ idx, const int* __restrict__ node_of, const uint32_t* __restrict__ flag,
+                                                      const uint32_t* __restrict__ scan, const SahAct* __restrict__ act, const SahSplit* __restrict__ split,
+                                                      const int2* __restrict__ child_act, uint32_t* __restrict__ idx2, int* __restrict__ node_of2) {
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int a = node_of[p];
+    if (a < 0) { idx2[p] = idx[p]; node_of2[p] = -1; return; }
+    const uint32_t lo = act[a].lo, left = split[a].left;
+    const uint32_t before = scan[p] - scan[lo];      // triangles of this node that go left and stand before p
+    const bool l = flag[p] != 0;
+    const uint32_t q = l ? lo + before : lo + left + ((p - lo) - before);
+    idx2[q] = idx[p];
+    const int2 ca = child_act[a];
+    node_of2[q] = l ? ca.x : ca.y;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -261,10 +401,10 @@ __device__ __forceinline__ float child_cost(const DpD* dp, int ref, float area, 
 }
 
 // bottom-up: a node is evaluated by the last of its inner children to finish (or at once if it has none)
-__global__ __launch_bounds__(256) void k_dp(const ErNode* __restrict__ nodes, uint32_t n_inner, const unsigned char* __restrict__ absorbed,
+__global__ __launch_bounds__(256) void k_dp(const ErNode* __restrict__ nodes, uint32_t n_inner,
                                              const int* __restrict__ parent_inner, DpD* dp, unsigned* arrived) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_inner || absorbed[i]) return;
+    if (i >= n_inner) return;
     if (nodes[i].c0 >= 0 || nodes[i].c1 >= 0) return;      // has inner children: one of them gets here
     while (true) {
         const ErNode nd = nodes[i];
@@ -512,66 +652,130 @@ struct GpuBuild {
     hipStream_t st = nullptr;
     Dev<float> d_v, d_n, d_lift;
     Dev<Box3> d_box;
-    Dev<unsigned long long> d_keys, d_keys2;
-    Dev<uint32_t> d_ids, d_ids2;
-    Dev<int2> d_children;
-    Dev<int> d_pi, d_pl;
+    Dev<uint32_t> d_ids2;       // slot -> triangle, the binary tree's order
+    Dev<int> d_pi;              // parent link of every inner node: parent * 2 + side
     Dev<ErNode> d_nodes;
-    Dev<unsigned> d_g, d_visits, d_heights;
-    Dev<char> d_tmp;
-    Dev<unsigned char> d_absorbed;
+    Dev<unsigned> d_g;
     unsigned g[12] = {0};
     ~GpuBuild() { if (st) (void)hipStreamDestroy(st); }
 
-    // stages 1-6 of the header comment; returns 0, > 0 (declined) or -1
+    // stages 1-2 of the header comment; returns 0, > 0 (declined) or -1
     int binary(const float* vertices, const float* normals, uint32_t n_, int device, std::string& err) {
         n = n_;
         n_inner = n - 1;
         const uint32_t blocks = (n + 255) / 256;
-        size_t tmp_bytes = 0;
         GB_OK(hipSetDevice(device));
         GB_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         GB_OK(hipMalloc(&d_v.p, (size_t)n * 36));
         GB_OK(hipMalloc(&d_n.p, (size_t)n * 36));
         GB_OK(hipMalloc(&d_lift.p, (size_t)n * 4));
         GB_OK(hipMalloc(&d_box.p, (size_t)n * sizeof(Box3)));
-        GB_OK(hipMalloc(&d_keys.p, (size_t)n * 8));
-        GB_OK(hipMalloc(&d_keys2.p, (size_t)n * 8));
-        GB_OK(hipMalloc(&d_ids.p, (size_t)n * 4));
         GB_OK(hipMalloc(&d_ids2.p, (size_t)n * 4));
-        GB_OK(hipMalloc(&d_children.p, (size_t)n_inner * sizeof(int2)));
         GB_OK(hipMalloc(&d_pi.p, (size_t)n * 4));
-        GB_OK(hipMalloc(&d_pl.p, (size_t)n * 4));
         GB_OK(hipMalloc(&d_nodes.p, (size_t)n_inner * sizeof(ErNode)));
         GB_OK(hipMalloc(&d_g.p, 12 * 4));
-        GB_OK(hipMalloc(&d_visits.p, (size_t)n_inner * 4));
-        GB_OK(hipMalloc(&d_heights.p, (size_t)n_inner * 4));
-        GB_OK(hipMalloc(&d_absorbed.p, (size_t)n_inner));
         GB_OK(hipMemcpyAsync(d_v.p, vertices, (size_t)n * 36, hipMemcpyHostToDevice, st));
         GB_OK(hipMemcpyAsync(d_n.p, normals, (size_t)n * 36, hipMemcpyHostToDevice, st));
-        // [0] vmax, [1..3] centroid lo (ordered), [4..6] centroid hi (ordered), [7] lift max, [8] max height, [9] leaf count
+        // [0] vmax, [7] lift max; [8] the deepest node's depth, [9] leaf count (set on the host by sah())
         for (int k = 0; k < 12; k++) g[k] = 0;
-        g[1] = g[2] = g[3] = 0xffffffffu;
         GB_OK(hipMemcpyAsync(d_g.p, g, sizeof(g), hipMemcpyHostToDevice, st));
-        GB_OK(hipMemsetAsync(d_visits.p, 0, (size_t)n_inner * 4, st));
-        GB_OK(hipMemsetAsync(d_heights.p, 0, (size_t)n_inner * 4, st));
         hipLaunchKernelGGL(k_scene_bounds, dim3(blocks), dim3(256), 0, st, d_v.p, n, d_g.p);
-        hipLaunchKernelGGL(k_prims, dim3(blocks), dim3(256), 0, st, d_v.p, d_n.p, n, d_g.p, d_box.p, d_lift.p, d_keys.p, d_ids.p, d_g.p + 7);
-        GB_OK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys.p, d_keys2.p, d_ids.p, d_ids2.p, n, 0, 63, st));
-        GB_OK(hipMalloc(&d_tmp.p, tmp_bytes ? tmp_bytes : 16));
-        GB_OK(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_keys.p, d_keys2.p, d_ids.p, d_ids2.p, n, 0, 63, st));
-        hipLaunchKernelGGL(k_tree, dim3((n_inner + 255) / 256), dim3(256), 0, st, d_keys2.p, n, d_children.p, d_pi.p, d_pl.p);
-        hipLaunchKernelGGL(k_refit, dim3(blocks), dim3(256), 0, st, d_box.p, d_ids2.p, n, d_children.p, d_pi.p, d_pl.p, d_nodes.p, d_visits.p,
-                           d_heights.p, d_g.p + 8);
-        hipLaunchKernelGGL(k_pair, dim3((n_inner + 255) / 256), dim3(256), 0, st, d_nodes.p, n_inner, d_g.p + 9);
-        hipLaunchKernelGGL(k_pair_commit, dim3((n_inner + 255) / 256), dim3(256), 0, st, d_nodes.p, n_inner, d_absorbed.p);
-        GB_OK(hipGetLastError());
-        GB_OK(hipMemcpyAsync(g, d_g.p, sizeof(g), hipMemcpyDeviceToHost, st));
-        GB_OK(hipStreamSynchronize(st));
+        hipLaunchKernelGGL(k_prims, dim3(blocks), dim3(256), 0, st, d_v.p, d_n.p, n, d_g.p, d_box.p, d_lift.p, d_g.p + 7);
+        int rc = sah(err);
+        if (rc != 0) return rc;
         if (g[8] + 1 > ER_BVH_MAX_DEPTH - 1) {
-            err = "linear BVH of depth " + std::to_string(g[8] + 1) + " exceeds the traversal stack bound";
+            err = "binary tree of depth " + std::to_string(g[8] + 1) + " exceeds the traversal stack bound";
             return 2;
         }
+        return 0;
+    }
+    // top-down binned SAH, one tree level per round (comment above k_sah_cen); leaves d_ids2 = slot -> triangle, d_nodes, d_pi, g[8], g[9]
+    int sah(std::string& err) {
+        const uint32_t blocks = (n + 255) / 256;
+        const uint32_t act_cap = n / (ER_BVH_LEAF_MAX + 1) + 2;                       // an active node holds more than ER_BVH_LEAF_MAX triangles
+        const uint32_t bin_cap = std::min<uint32_t>(act_cap, 1u << 20);               // bins for this many nodes at a time (1.3 GB); a fuller round runs in chunks
+        Dev<float> d_cen;
+        Dev<uint32_t> d_idx[2], d_flag, d_scan, d_kids, d_koff;
+        Dev<int> d_nof[2];
+        Dev<SahAct> d_act[2];
+        Dev<SahSplit> d_split;
+        Dev<int2> d_cact;
+        Dev<unsigned> d_cbv, d_bins, d_tot;
+        Dev<char> d_st;
+        GB_OK(hipMalloc(&d_cen.p, (size_t)n * 12));
+        for (int k = 0; k < 2; k++) {
+            GB_OK(hipMalloc(&d_idx[k].p, (size_t)n * 4));
+            GB_OK(hipMalloc(&d_nof[k].p, (size_t)n * 4));
+            GB_OK(hipMalloc(&d_act[k].p, (size_t)act_cap * sizeof(SahAct)));
+        }
+        GB_OK(hipMalloc(&d_flag.p, (size_t)n * 4));
+        GB_OK(hipMalloc(&d_scan.p, (size_t)n * 4));
+        GB_OK(hipMalloc(&d_kids.p, (size_t)act_cap * 4));
+        GB_OK(hipMalloc(&d_koff.p, (size_t)act_cap * 4));
+        GB_OK(hipMalloc(&d_split.p, (size_t)act_cap * sizeof(SahSplit)));
+        GB_OK(hipMalloc(&d_cact.p, (size_t)act_cap * sizeof(int2)));
+        GB_OK(hipMalloc(&d_cbv.p, (size_t)act_cap * 6 * 4));
+        GB_OK(hipMalloc(&d_bins.p, (size_t)bin_cap * SAH_NODE_WORDS * 4));
+        GB_OK(hipMalloc(&d_tot.p, 8));
+        size_t sb1 = 0, sb2 = 0;
+        GB_OK(rocprim::exclusive_scan(nullptr, sb1, d_flag.p, d_scan.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+        GB_OK(rocprim::exclusive_scan(nullptr, sb2, d_kids.p, d_koff.p, 0u, (size_t)act_cap, rocprim::plus<uint32_t>(), st));
+        const size_t scan_bytes = std::max(sb1, sb2);
+        GB_OK(hipMalloc(&d_st.p, scan_bytes ? scan_bytes : 16));
+        hipLaunchKernelGGL(k_sah_cen, dim3(blocks), dim3(256), 0, st, d_v.p, n, d_cen.p);
+        hipLaunchKernelGGL(k_sah_init, dim3(blocks), dim3(256), 0, st, n, d_idx[0].p, d_nof[0].p);
+        GB_OK(hipMemcpyAsync(g, d_g.p, sizeof(g), hipMemcpyDeviceToHost, st));
+        GB_OK(hipStreamSynchronize(st));
+        SahAct root;
+        root.node = 0; root.lo = 0; root.hi = n; root.depth = 0;
+        {   // (the root's box is only read if every centroid of the scene coincides: any box that holds the scene will do)
+            float vmax; memcpy(&vmax, &g[0], 4);
+            const float r = vmax * 1.00001f + 1e-30f;
+            for (int m = 0; m < 3; m++) { root.blo[m] = -r; root.bhi[m] = r; }
+        }
+        GB_OK(hipMemcpyAsync(d_act[0].p, &root, sizeof(root), hipMemcpyHostToDevice, st));
+        uint32_t n_act = 1, created = 1, leaves = 0, depth = 0;
+        int cur = 0;
+        while (n_act > 0) {
+            depth++;
+            if (depth > ER_BVH_MAX_DEPTH) { err = "binned-SAH build deeper than its own guard allows"; return -1; }
+            const uint32_t ab = (n_act + 255) / 256;
+            const size_t clear_items = std::max((size_t)n_act * 6, (size_t)std::min(n_act, bin_cap) * SAH_NODE_WORDS);
+            hipLaunchKernelGGL(k_sah_clear, dim3((unsigned)((clear_items + 255) / 256)), dim3(256), 0, st, d_cbv.p, n_act, d_bins.p, std::min(n_act, bin_cap));
+            hipLaunchKernelGGL(k_sah_cb, dim3(blocks), dim3(256), 0, st, n, d_idx[cur].p, d_nof[cur].p, d_cen.p, d_cbv.p);
+            for (uint32_t a0 = 0; a0 < n_act; a0 += bin_cap) {
+                const uint32_t a1 = std::min(n_act, a0 + bin_cap);
+                if (a0 > 0) hipLaunchKernelGGL(k_sah_clear, dim3((unsigned)(((size_t)(a1 - a0) * SAH_NODE_WORDS + 255) / 256)), dim3(256), 0, st, d_cbv.p, 0u, d_bins.p, a1 - a0);
+                hipLaunchKernelGGL(k_sah_bin, dim3(blocks), dim3(256), 0, st, n, d_idx[cur].p, d_nof[cur].p, d_cen.p, d_box.p, d_cbv.p, d_bins.p, (int)a0, (int)a1);
+                hipLaunchKernelGGL(k_sah_split, dim3((a1 - a0 + 63) / 64), dim3(64), 0, st, d_act[cur].p, d_cbv.p, d_bins.p, (int)a0, (int)a1, d_split.p, d_nodes.p);
+            }
+            hipLaunchKernelGGL(k_sah_count, dim3(ab), dim3(256), 0, st, d_split.p, n_act, d_kids.p);
+            size_t sb = scan_bytes;
+            GB_OK(rocprim::exclusive_scan(d_st.p, sb, d_kids.p, d_koff.p, 0u, (size_t)n_act, rocprim::plus<uint32_t>(), st));
+            GB_OK(hipMemsetAsync(d_tot.p, 0, 8, st));
+            hipLaunchKernelGGL(k_sah_children, dim3(ab), dim3(256), 0, st, d_act[cur].p, d_split.p, d_koff.p, n_act, created, d_nodes.p, d_pi.p, d_act[cur ^ 1].p, d_cact.p, d_tot.p);
+            hipLaunchKernelGGL(k_sah_flags, dim3(blocks), dim3(256), 0, st, n, d_idx[cur].p, d_nof[cur].p, d_cen.p, d_act[cur].p, d_split.p, d_cbv.p, d_flag.p);
+            sb = scan_bytes;
+            GB_OK(rocprim::exclusive_scan(d_st.p, sb, d_flag.p, d_scan.p, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+            hipLaunchKernelGGL(k_sah_scatter, dim3(blocks), dim3(256), 0, st, n, d_idx[cur].p, d_nof[cur].p, d_flag.p, d_scan.p, d_act[cur].p, d_split.p, d_cact.p,
+                               d_idx[cur ^ 1].p, d_nof[cur ^ 1].p);
+            unsigned tot[2] = {0, 0};
+            GB_OK(hipMemcpyAsync(tot, d_tot.p, 8, hipMemcpyDeviceToHost, st));
+            GB_OK(hipStreamSynchronize(st));
+            created += tot[0];
+            leaves += tot[1];
+            if (created > n_inner || tot[0] > act_cap) { err = "binned-SAH build made more nodes than triangles"; return -1; }
+            n_act = tot[0];
+            cur ^= 1;
+        }
+        GB_OK(hipGetLastError());
+        // slot -> triangle: the final order of the triangles (the rest of the build reads it from d_ids2)
+        GB_OK(hipMemcpyAsync(d_ids2.p, d_idx[cur].p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        GB_OK(hipStreamSynchronize(st));
+        n_inner = created;                 // (two-triangle leaves come out directly: fewer than n - 1 nodes)
+        g[8] = depth - 1;                  // the deepest node's depth; the check in binary() adds the leaf level
+        g[9] = leaves;
+        if (getenv("ER_GPU_BUILD_VERBOSE")) fprintf(stderr, "[er_gpu_build] binned SAH on the device: %u triangles, %u levels, %u nodes, %u leaves\n", n, depth, created, leaves);
         return 0;
     }
     float lift_bound() const { float lm; memcpy(&lm, &g[7], 4); return lm; }
@@ -599,7 +803,7 @@ int er_gpu_build_device(const ErGpuSceneArrays& a, uint32_t n, int device, ErGpu
     GB_OK(hipMalloc(&d_dp.p, (size_t)n_inner * sizeof(DpD)));
     GB_OK(hipMalloc(&d_arrived.p, (size_t)n_inner * 4));
     GB_OK(hipMemsetAsync(d_arrived.p, 0, (size_t)n_inner * 4, st));
-    hipLaunchKernelGGL(k_dp, dim3((n_inner + 255) / 256), dim3(256), 0, st, B.d_nodes.p, n_inner, B.d_absorbed.p, B.d_pi.p, d_dp.p, d_arrived.p);
+    hipLaunchKernelGGL(k_dp, dim3((n_inner + 255) / 256), dim3(256), 0, st, B.d_nodes.p, n_inner, B.d_pi.p, d_dp.p, d_arrived.p);
     // ---- breadth-first emission of the wide nodes, one level per iteration ----
     Dev<WorkD> d_work[2];
     Dev<uint32_t> d_ci, d_ti, d_co, d_to, d_new_order, d_inv, d_s2t;

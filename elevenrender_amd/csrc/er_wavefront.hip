@@ -264,13 +264,12 @@ __global__ __launch_bounds__(64, WF_TRACE_WAVES) void er_wf_trace(DevScene S, Wf
 #endif
 template <bool COUNT, bool EXT>
 __global__ __launch_bounds__(64, WF_SHADE_WAVES) void er_wf_shade(DevScene S, WfState W, uint32_t parity) {
-    __shared__ int s_stack[ER_STACK * 64];   // only for the rare exact re-trace of an overflowed ray
     // queue entries are staged per wave and appended WF_STAGE tickets at a time: the two queue-length words are
     // single addresses, and one address takes ~90 atomics/us whatever the number of waves
     __shared__ uint32_t s_qc[WF_STAGE * 64], s_qs[WF_STAGE * 64];
     unsigned n_qc = 0, n_qs = 0;             // staged entries (wave-uniform)
     const int lane = threadIdx.x;
-    int* stack = s_stack + lane;
+    int* stack = W.shade_stack + (size_t)blockIdx.x * (ER_STACK * 64) + lane;      // only for the rare exact re-trace of an overflowed ray
     unsigned c_nodes = 0, c_tris = 0;
     const uint32_t nC = W.counts[WF_NC + WF_PAR(parity)];
     if (blockIdx.x == 0 && lane < 8) W.counts[WF_TT + lane * WF_LINE] = 0;

@@ -126,9 +126,12 @@ typedef struct ErSceneDesc {
 #define ER_FLAG_STREAM       256u /* one launch per call, one resident workgroup per CU: tracer waves and shader waves feed each
                                      other through rings in LDS (er_stream.hip) */
 #define ER_FLAG_PROFILE      8u   /* bracket every trace / shade launch with HIP events (see er_get_profile) */
-#define ER_FLAG_GPU_BUILD    64u  /* build the acceleration structure on the GPU (linear BVH: several times faster to
-                                     build, slower to trace; falls back to the host SAH build if the tree would be too
-                                     deep).  Images do not depend on the builder. */
+/* Acceleration-structure builder.  Default since round 5: the DEVICE build (top-down binned SAH on the GPU, the host builder's own
+ * algorithm and tree: 65 ms instead of 0.43 s at 1 M triangles, 0.33 s instead of 5.0 s at 10 M) for scenes of at least
+ * ER_GPU_BUILD_MIN_TRIS (20 000; environment variable of that name) triangles, the host build below that; a device build that
+ * declines or fails falls back to the host build.  Images do not depend on the builder. */
+#define ER_FLAG_GPU_BUILD    64u  /* force the device build whatever the triangle count (an error of it is then the call's error) */
+#define ER_FLAG_HOST_BUILD   512u /* force the host build (er_bvh.cpp) */
 
 /* reference RenderParameters (src/kernel.h:51-69) + what the MI355X build adds. */
 typedef struct ErRenderParams {
@@ -280,7 +283,7 @@ typedef struct ErAccelInfo {
     uint32_t tri_record_bytes;         /* bytes fetched per triangle test */
     float build_ms, upload_ms;
     float lift_bound;                  /* global bound on |shadingPosition - geomPosition| */
-    uint32_t builder;                  /* 0 = host binned-SAH build, 1 = device linear-BVH build (ER_FLAG_GPU_BUILD) */
+    uint32_t builder;                  /* 0 = host binned-SAH build, 1 = device binned-SAH build */
 } ErAccelInfo;
 int er_accel_info(ErScene* scene, ErAccelInfo* out);
 

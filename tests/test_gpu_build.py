@@ -1,7 +1,8 @@
-"""the device-side BVH builder (ER_FLAG_GPU_BUILD, er_gpu_build.hip).
+"""the device-side BVH builder (er_gpu_build.hip; since round 5 the host builder's binned SAH, level by level on
+the GPU, and the default for scenes of >= 20 000 triangles; ER_FLAG_GPU_BUILD / ER_FLAG_HOST_BUILD force one).
 
 The contract of an acceleration structure is "same nearest hit", so the image must not depend on who built the
-tree: the device linear-BVH build against the host binned-SAH build, bit for bit, and against the oracle."""
+tree: the device build against the host build, bit for bit, and against the oracle."""
 import numpy as np
 import pytest
 
@@ -29,9 +30,10 @@ def test_device_built_bvh_gives_the_same_image(kind):
         sc = scenes.cornell(64, 48)
     else:
         sc = scenes.torture(6000, 80, 60, seed=6, n_materials=8, tex_size=16, hdri_size=(64, 32))
-    assert _accel(sc, abi.FLAG_GPU_BUILD)["builder"] == 1 and _accel(sc, 0)["builder"] == 0
+    assert _accel(sc, abi.FLAG_GPU_BUILD)["builder"] == 1 and _accel(sc, abi.FLAG_HOST_BUILD)["builder"] == 0
+    assert _accel(sc, 0)["builder"] == (1 if sc.tri_count >= 20000 else 0)        # the default goes by the triangle count
     for sched in (abi.FLAG_WAVEFRONT, abi.FLAG_FUSED, abi.FLAG_MEGAKERNEL, abi.FLAG_STREAM):
-        h = gpu_render(sc, 4, max_bounces=8, flags=sched)
+        h = gpu_render(sc, 4, max_bounces=8, flags=sched | abi.FLAG_HOST_BUILD)
         d = gpu_render(sc, 4, max_bounces=8, flags=sched | abi.FLAG_GPU_BUILD)
         for p in ("beauty", "normal", "tangent", "bitangent"):
             same = (h[p].view(np.uint32) == d[p].view(np.uint32)).all(-1)
@@ -49,23 +51,24 @@ def test_device_built_bvh_against_oracle(oracle_mod):
 
 
 def test_device_builder_full_size():
-    """1M triangles: the device build is several times faster than the host build and the window of tiles rendered
-    through it equals the one rendered through the host-built tree."""
+    """1M triangles: the device build is several times faster than the host build, makes a tree of the same size (it is the same
+    algorithm: node counts may differ by float rounding of the bins only), and the window of tiles rendered through it equals the one
+    rendered through the host-built tree."""
     sc = scenes.soup(1_000_000, 1920, 1080, seed=12345)
-    dev, host = _accel(sc, abi.FLAG_GPU_BUILD), _accel(sc, 0)
+    dev, host = _accel(sc, 0), _accel(sc, abi.FLAG_HOST_BUILD)
     print(f"build: device {dev['build_ms']:.0f} ms ({dev['node_count']} wide nodes, depth {dev['max_depth']}), "
           f"host {host['build_ms']:.0f} ms ({host['node_count']} wide nodes, depth {host['max_depth']})")
-    assert dev["builder"] == 1
-    a = gpu_render(sc, 2, max_bounces=8, rank=3, world=64)
-    b = gpu_render(sc, 2, max_bounces=8, rank=3, world=64, flags=abi.FLAG_GPU_BUILD)
+    assert dev["builder"] == 1 and host["builder"] == 0
+    assert abs(int(dev["node_count"]) - int(host["node_count"])) <= host["node_count"] // 100 and abs(int(dev["leaf_count"]) - int(host["leaf_count"])) <= host["leaf_count"] // 100
+    a = gpu_render(sc, 2, max_bounces=8, rank=3, world=64, flags=abi.FLAG_HOST_BUILD)
+    b = gpu_render(sc, 2, max_bounces=8, rank=3, world=64)
     same = (a["beauty"].view(np.uint32) == b["beauty"].view(np.uint32)).all(-1)
     assert same.mean() >= 0.9995
     assert a["counters"]["paths"] == b["counters"]["paths"]
 
 
 def test_device_builder_on_clustered_geometry():
-    """Tight far-apart clusters (long common Morton prefixes, a deep linear BVH): same image as the host-built tree;
-    if the device tree were too deep for the traversal stacks the library falls back to the host build by itself."""
+    """Tight far-apart clusters (most bins of the top splits are empty): same image as the host-built tree."""
     sc = scenes.soup(6000, 96, 72, seed=31, hdri_size=(64, 32))
     v = sc.vertices.reshape(-1, 3, 3).copy()
     c = v.mean(1, keepdims=True)
@@ -74,7 +77,33 @@ def test_device_builder_on_clustered_geometry():
     v = centre + (v - c) * 0.2 + (c - c.mean(0)) * 1e-3         # each cluster ~2 mm across
     sc.vertices = np.ascontiguousarray(v.reshape(sc.vertices.shape).astype(np.float32))
     sc._desc = None
-    h = gpu_render(sc, 3, max_bounces=8)
+    h = gpu_render(sc, 3, max_bounces=8, flags=abi.FLAG_HOST_BUILD)
     d = gpu_render(sc, 3, max_bounces=8, flags=abi.FLAG_GPU_BUILD)
     same = (h["beauty"].view(np.uint32) == d["beauty"].view(np.uint32)).all(-1)
     assert same.mean() >= 0.999, float(same.mean())
+
+
+def test_device_builder_on_coincident_centroids_and_tiny_scenes():
+    """Degenerate inputs of the split: every triangle's centroid in one place (no axis to bin on: the range is halved by position
+    under the node's whole box), three triangles (one split), and duplicates of one triangle -- through the forced device build,
+    against the host build."""
+    base = scenes.soup(64, 64, 48, seed=5, hdri_size=(32, 16))
+    v = base.vertices.reshape(-1, 3, 3).copy()
+    for variant in ("same-centroid", "three", "duplicates"):
+        sc = scenes.soup(64, 64, 48, seed=5, hdri_size=(32, 16))
+        w = v.copy()
+        if variant == "same-centroid":
+            w = w - w.mean(1, keepdims=True) + np.array([0.0, 0.0, 3.0], np.float32)      # all centroids at (0, 0, 3), to rounding
+            w[:, :, :] = np.round(w * 64) / 64                                             # ... exactly representable: centroids bit-equal for many
+        elif variant == "duplicates":
+            w[:] = w[0]
+        if variant == "three":
+            sc = scenes.soup(3, 64, 48, seed=5, hdri_size=(32, 16))
+        else:
+            sc.vertices = np.ascontiguousarray(w.reshape(sc.vertices.shape).astype(np.float32))
+            sc._desc = None
+        h = gpu_render(sc, 2, max_bounces=4, flags=abi.FLAG_HOST_BUILD)
+        d = gpu_render(sc, 2, max_bounces=4, flags=abi.FLAG_GPU_BUILD)
+        same = (h["beauty"].view(np.uint32) == d["beauty"].view(np.uint32)).all(-1)
+        assert same.mean() >= 0.995, (variant, float(same.mean()))      # (coincident triangles: exact ties are resolved by tree order)
+        assert (h["samples"] == d["samples"]).all()
