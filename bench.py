@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_TAG = "r04"     # profiles/<tag>_pmc_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
+PROFILE_TAG = "r05"     # profiles/<tag>_pmc_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
 
 
 def trace_bytes(c):
@@ -485,7 +485,7 @@ def main():
         standard = args.tris == 1_000_000 and not (args.width or args.height) and not args.max_bounces and world == 1 and shard_world == 1
         cfg_key = args.config + ("_nolights" if args.config == "C5" and args.no_lights else "")
         if sched == "stream" and standard:
-            for tag in (PROFILE_TAG, "r03"):
+            for tag in (PROFILE_TAG, "r04"):
                 tf = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
                 if not os.path.exists(tf):
                     continue

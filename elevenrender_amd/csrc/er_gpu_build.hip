@@ -116,7 +116,9 @@ __global__ __launch_bounds__(256) void k_prims(const float* __restrict__ v, cons
 // The radix tree over Morton codes of round 1 and a locally-ordered clustering (profiles/r05_ab_builder_ploc.log, r05_ab_device_sah_builder.log)
 // make trees that a ray visits 5 % / 20 % more nodes of.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef SAH_BINS
 #define SAH_BINS 16
+#endif
 #define SAH_BIN_WORDS 7                                   // count, lo[3], hi[3] (order-preserving integers)
 #define SAH_NODE_WORDS (3 * SAH_BINS * SAH_BIN_WORDS)     // 336 words = 1 344 bytes of bins per active node
 
