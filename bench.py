@@ -379,15 +379,19 @@ def main():
                     "bounce_samples": [int(e[1]) for e in em], "paths": [int(e[2]) for e in em], "rays": [int(e[3]) for e in em]}
 
     # ---- framebuffer combine (once per read-back, outside the timed region) ----
+    # It runs on a worker thread with a deadline: RCCL from the library's C++ side has never run with more than one rank on the
+    # machines this was built on, and a communicator that never forms must not cost the run its measurement -- after
+    # ER_BENCH_GATHER_TIMEOUT seconds (180) rank 0 prints the line with `gather` saying so and the process exits with code 5.
     t_rb = time.perf_counter()
-    gather_path = None
-    gather_ms = None
-    if dist is not None:
+    gstate = {"path": None, "ms": None, "error": None}
+
+    def do_gather():
         from elevenrender_amd import dist as erdist
-        if rehearsal:
-            erdist.gather_all_planes_torch(dist, rm, rank, world)     # gloo on the host: the test harness path
-            gather_path = "torch.distributed (gloo rehearsal)"
-        else:
+        try:
+            if rehearsal:
+                erdist.gather_all_planes_torch(dist, rm, rank, world)     # gloo on the host: the test harness path
+                gstate["path"] = "torch.distributed (gloo rehearsal)"
+                return
             # the production combine: RCCL communicator made by the library's C++ side (er_comm_create), then per plane
             # er_gather_pass = pack -> ncclSend / ncclRecv over xGMI -> unpack.  If the C++ path cannot start on this
             # node (RCCL not loadable ...) every rank falls back to the torch.distributed gather so that the line is
@@ -403,16 +407,31 @@ def main():
                 for p in range(abi.PASS_COUNT):
                     comm.gather_pass(rm, p)
                 sync_all()
-                gather_ms = (time.perf_counter() - t_g) * 1e3      # pack + send/recv over xGMI + unpack of all five planes, slowest rank
-                gather_path = "er_gather_pass (RCCL from the C++ side, 5 planes)"
+                gstate["ms"] = (time.perf_counter() - t_g) * 1e3      # pack + send/recv over xGMI + unpack of all five planes, slowest rank
+                gstate["path"] = "er_gather_pass (RCCL from the C++ side, 5 planes)"
+                comm.close()
             else:
                 erdist.gather_all_planes_torch(dist, rm, rank, world)
-                gather_path = "torch.distributed.gather (fallback: er_comm_create failed)"
-            if comm is not None:
-                comm.close()
-        torch.cuda.synchronize()
+                gstate["path"] = "torch.distributed.gather (fallback: er_comm_create failed)"
+            torch.cuda.synchronize()
+        except Exception as e:      # (reported in the line; the throughput measurement above stands)
+            gstate["error"] = f"{type(e).__name__}: {e}"
+
+    gather_hung = False
+    if dist is not None:
+        import threading
+        th = threading.Thread(target=do_gather, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("ER_BENCH_GATHER_TIMEOUT", "180")))
+        gather_hung = th.is_alive()
+        if gather_hung:
+            gstate["path"] = "NOT COMPLETED: the framebuffer gather did not return within its deadline (the throughput figures above do not depend on it)"
+        elif gstate["error"]:
+            gstate["path"] = "FAILED: " + gstate["error"]
+    gather_path, gather_ms = gstate["path"], gstate["ms"]
+    gather_ok = dist is None or (not gather_hung and not gstate["error"])
     beauty_mean = None
-    if rank == 0:
+    if rank == 0 and gather_ok:
         img = rm.get_pass("beauty")
         assert np.isfinite(img).all()
         beauty_mean = float(img[..., :3].mean())
@@ -600,6 +619,14 @@ def main():
             # of rows on all cores; the one-core leg would need a second build and is left out there
             result["cpu_baseline"] = cpu_baseline(scene, max_bounces, ext_flags, threads, args.cpu_budget, one_core=args.config != "C4")
             result["gpu_over_cpu"] = round(value / max(result["cpu_baseline"]["value"], 1e-12), 1)
+    if not gather_ok:
+        # a rank is (or may be) stuck inside a collective: say what was measured and leave without touching the process group again
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        else:
+            time.sleep(float(os.environ.get("ER_BENCH_EXIT_GRACE", "45")))      # (a launcher ends every rank when one leaves with an error: rank 0 prints its line first)
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(5)
     rm.close()
     if dist is not None:
         dist.barrier()

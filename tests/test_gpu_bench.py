@@ -54,3 +54,16 @@ def test_bench_gpus_2_without_a_launcher_runs_two_ranks():
     assert sum(line["ranks"]["paths"]) == 256 * 192 * 3           # the two shares make the frame, once
     assert line["gather"] and "gloo" in line["gather"]
     assert line["config"]["sharding"].endswith("% 2") and line["scaling"] == "strong"
+
+
+def test_a_gather_that_does_not_return_costs_the_run_its_exit_code_not_its_measurement():
+    """The framebuffer gather of a multi-rank bench runs under a deadline (RCCL from the library's C++ side has never run with more than
+    one rank where this was built): with the deadline set to nothing the line is still printed, with `gather` saying that the combine was
+    not completed, and the process leaves with code 5."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(ER_BENCH_REHEARSAL="1", ER_BENCH_GATHER_TIMEOUT="0.000001", ER_BENCH_EXIT_GRACE="8")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SMALL, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode != 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "NOT COMPLETED" in line["gather"]
