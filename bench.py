@@ -215,7 +215,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline's all-core leg (0 = every core this job may use)")
     ap.add_argument("--no-trace-phase", action="store_true", help="skip the single-pool pass that measures the traversal phase alone")
     ap.add_argument("--per-step-launch", action="store_true", help="one launch per step instead of one launch for all K steps")
-    ap.add_argument("--schedule", choices=["auto", "wavefront", "fused", "megakernel", "stream"], default="auto")
+    ap.add_argument("--schedule", choices=["auto", "wavefront", "megakernel", "stream"], default="auto")
     ap.add_argument("--gpu-build", action="store_true", help="force the device BVH build (ER_FLAG_GPU_BUILD; the default for scenes of >= 20 000 triangles since round 5)")
     ap.add_argument("--host-build", action="store_true", help="force the host BVH build (ER_FLAG_HOST_BUILD)")
     ap.add_argument("--sim-world", type=int, default=0, help="(diagnostic) render only rank --sim-rank's tiles of this many, no collective")
@@ -261,7 +261,7 @@ def main():
 
     scene, ext_flags, workload = make_scene(args, scenes, abi)
     shard_rank, shard_world = (args.sim_rank, args.sim_world) if (args.sim_world > 1 and world == 1) else (rank, world)
-    sched_flag = {"auto": 0, "wavefront": abi.FLAG_WAVEFRONT, "fused": abi.FLAG_FUSED, "megakernel": abi.FLAG_MEGAKERNEL, "stream": abi.FLAG_STREAM}[args.schedule]
+    sched_flag = {"auto": 0, "wavefront": abi.FLAG_WAVEFRONT, "megakernel": abi.FLAG_MEGAKERNEL, "stream": abi.FLAG_STREAM}[args.schedule]
     base_flags = sched_flag | ext_flags | (abi.FLAG_GPU_BUILD if args.gpu_build else 0) | (abi.FLAG_HOST_BUILD if args.host_build else 0)
 
     def manager(extra_flags):
@@ -454,8 +454,8 @@ def main():
         path_b = path_bytes(ci, hdri_texels) / max(1, ci["bounce_samples"]) * my_samples
         t_launches = max(1, prof["trace_launches"])
         trace_ms_avg = prof["trace_ms"] / t_launches
-        sched = {abi.FLAG_WAVEFRONT: "wavefront", abi.FLAG_FUSED: "fused", abi.FLAG_MEGAKERNEL: "megakernel", abi.FLAG_STREAM: "stream"}.get(prof["schedule"], "?")
-        kernel_name = {"wavefront": "er_wf_trace", "fused": "er_fused_kernel", "megakernel": "er_render_kernel", "stream": "er_stream_kernel"}.get(sched, "?")
+        sched = {abi.FLAG_WAVEFRONT: "wavefront", abi.FLAG_MEGAKERNEL: "megakernel", abi.FLAG_STREAM: "stream"}.get(prof["schedule"], "?")
+        kernel_name = {"wavefront": "er_wf_trace", "megakernel": "er_render_kernel", "stream": "er_stream_kernel"}.get(sched, "?")
         if sched not in ("wavefront", "stream"):
             layout_b = path_b + (layout_b - trace_b)
             trace_b = path_b      # the single kernel of these schedules does the whole path

@@ -405,45 +405,32 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     if ((rc = upload(s->d_owned, owned.data(), owned.size(), s->stream)) != ER_OK) return rc;
     if ((rc = upload(s->d_counters, nullptr, 1, s->stream)) != ER_OK) return rc;
     HIP_TRY(hipMemsetAsync(s->d_counters.p, 0, sizeof(DevCounters), s->stream));
-    // schedule: forced by a flag, else by how many pixels this rank owns (see eleven_hip.h)
+    // schedule: forced by a flag, else the streaming schedule unless this rank's share is beyond its pixel rings (see eleven_hip.h)
     {
-        const uint32_t forced = p->flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM);
+        uint32_t forced = p->flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM);
+        // (ER_FLAG_FUSED named round 1's lane-asynchronous single kernel, which the streaming schedule has overtaken at every frame size --
+        // C1 at 256 x 256: 1 186 against 849 Msamples/s, profiles/r05_schedules_small_frames.log -- and which round 5 removed: the flag
+        // is still accepted and means the streaming schedule)
+        if (forced == ER_FLAG_FUSED) forced = ER_FLAG_STREAM;
         uint32_t sched = forced;
-        // measured on MI355X (profiles/r02_schedules_by_size.log): the streaming schedule wins from ~0.2 M owned pixels up on scenes
-        // whose traversal data fit the Infinity Cache (1 M-triangle soup: 640x360 to 3840x2160, also 1/2 .. 1/8 shares of a
-        // 1080p frame); the wavefront schedule keeps the 4K frame of the 9.68 M-triangle scene (C4); the fused kernel the
-        // small frames, which are launch-bound
         if (forced == 0) {
-            const size_t px = owned.size() * 64;
             int cus = 1;
             HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
             cus = std::max(1, cus);
-            if (px < 150000u) sched = ER_FLAG_FUSED;
-            else {
-                // beyond the streaming schedule's pixel rings -> wavefront.  Decided on the REAL deal of tiles to workgroups, not on an
-                // estimate of its largest share: the XCD-aware deal hands out whole super-tiles and can be less balanced than
-                // ceil(tiles / CUs) (near the limit the estimate chose ER_FLAG_STREAM and er_render_begin then failed
-                // with INVALID_ARG instead of taking the other schedule)
-                std::vector<uint32_t> deal;
-                const uint32_t most = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), (s->x_res + ER_TILE - 1) / ER_TILE, (uint32_t)cus,
-                                                           stream_xcd_aware(owned.size(), (uint32_t)cus), deal);
-                // (and the streaming schedule carries a pixel as px | py << 16)
-                sched = ((size_t)most * 64u > ER_STREAM_MAX_RING || s->x_res > 65535u || s->y_res > 65535u) ? ER_FLAG_WAVEFRONT : ER_FLAG_STREAM;
-            }
+            // beyond the streaming schedule's pixel rings -> wavefront.  Decided on the REAL deal of tiles to workgroups, not on an
+            // estimate of its largest share: the XCD-aware deal hands out whole super-tiles and can be less balanced than
+            // ceil(tiles / CUs) (near the limit the estimate chose ER_FLAG_STREAM and er_render_begin then failed
+            // with INVALID_ARG instead of taking the other schedule)
+            std::vector<uint32_t> deal;
+            const uint32_t most = er_stream_deal_tiles(owned.data(), (uint32_t)owned.size(), (s->x_res + ER_TILE - 1) / ER_TILE, (uint32_t)cus,
+                                                       stream_xcd_aware(owned.size(), (uint32_t)cus), deal);
+            // (and the streaming schedule carries a pixel as px | py << 16)
+            sched = ((size_t)most * 64u > ER_STREAM_MAX_RING || s->x_res > 65535u || s->y_res > 65535u) ? ER_FLAG_WAVEFRONT : ER_FLAG_STREAM;
         }
         else if (forced & (forced - 1)) return fail(ER_ERR_INVALID_ARG, "er_render_begin: more than one schedule flag");
         s->params.flags = (s->params.flags & ~(uint32_t)(ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM)) | sched;
     }
-    if (s->params.flags & ER_FLAG_FUSED) {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, s->device));
-        s->fused_blocks = (uint32_t)prop.multiProcessorCount * 12;   // 3 waves per SIMD (register-limited, see er_fused.hip)
-        if (const char* e = getenv("ER_FUSED_WAVES_PER_CU")) s->fused_blocks = (uint32_t)prop.multiProcessorCount * (uint32_t)std::max(1, atoi(e));
-        // per wave: ER_BVH_MAX_DEPTH x 64 uint2 stack entries + the same number of ints for the exact re-trace
-        if ((rc = upload(s->d_spill, nullptr, (size_t)s->fused_blocks * ER_BVH_MAX_DEPTH * 64 * 3 / 2, s->stream)) != ER_OK) return rc;
-        // per-wave rings of (slot, samples left) records: capacity ceil(chunks / waves) * 4 each
-        if ((rc = upload(s->d_ticket, nullptr, (owned.size() * 64 + 4 * (size_t)s->fused_blocks) * 2, s->stream)) != ER_OK) return rc;
-    } else if (s->params.flags & ER_FLAG_STREAM) {
+    if (s->params.flags & ER_FLAG_STREAM) {
         // streaming schedule: one workgroup per CU with ER_STREAM_SLOTS slots of the wavefront schedule's records each
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, s->device));
@@ -689,7 +676,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     }
     if (n > 0) for (auto& u : s->unpacked) u.clear();     // other ranks' pixels gathered earlier are stale from here on
     const bool count = (s->params.flags & ER_FLAG_COUNTERS) != 0;
-    const bool single = (s->params.flags & (ER_FLAG_FUSED | ER_FLAG_MEGAKERNEL | ER_FLAG_STREAM)) != 0;
+    const bool single = (s->params.flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_STREAM)) != 0;
     if (single && (s->params.flags & ER_FLAG_PROFILE) && n > 0) {
         while (s->prof_events.size() < s->prof_used + 3) {
             hipEvent_t e;
@@ -698,9 +685,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
         }
         HIP_TRY(hipEventRecord(s->prof_events[s->prof_used++], s->stream));
     }
-    if (s->params.flags & ER_FLAG_FUSED) {
-        er_launch_fused(s->dev, s->d_ticket.p, s->d_spill.p, n, count, s->fused_blocks, s->stream);
-    } else if (s->params.flags & ER_FLAG_STREAM) {
+    if (s->params.flags & ER_FLAG_STREAM) {
         HIP_TRY(hipMemsetAsync(s->stream_ctl + 2, 0, 22 * sizeof(uint32_t), s->stream));      // the call's lane-occupancy counts, its end per XCD ...
         HIP_TRY(hipMemsetAsync(s->stream_ctl + 6, 0xFF, 2 * sizeof(uint32_t), s->stream));    // ... and its start (a minimum)
         if (n > 0) s->stream_launches++;
@@ -876,7 +861,7 @@ static int er_wait_impl(ErScene* s, float* elapsed_ms) {
     { int rc = er_scene_stream_status(s, "er_wait"); if (rc != ER_OK) { s->prof_used = 0; return rc; } }   // (the profiling window ends with the call either way)
     er_stream_adapt(s);
     s->profile = ErProfile{};
-    s->profile.schedule = s->params.flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_FUSED | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM);
+    s->profile.schedule = s->params.flags & (ER_FLAG_MEGAKERNEL | ER_FLAG_WAVEFRONT | ER_FLAG_STREAM);
     s->profile.concurrency = (s->params.flags & ER_FLAG_WAVEFRONT) ? (uint32_t)std::max<size_t>(1, s->wf.size()) : 1u;
     // The wavefront host loop always enqueues n * (max_bounces + 1) iterations per pool; the last ones find empty
     // queues (a path rarely takes every bounce).  Those launches are reported apart, so that per-launch figures are

@@ -10,7 +10,6 @@ void er_launch_setup(const DevScene& S, hipStream_t stream);
 // device can run (*which names the first kernel that failed).  Called by er_render_begin before the first launch.
 hipError_t er_probe_kernels(const char** which);
 hipError_t er_probe_wavefront(const char** which);
-hipError_t er_probe_fused(const char** which);
 hipError_t er_probe_gpu_build(const char** which);
 void er_launch_atrous(const float4* src, int src_stride, const float4* normal, int normal_stride, float4* dst, int w, int h, int step, float kc, hipStream_t stream);
 void er_launch_plane(const DevScene& S, int pass, float4* dst, hipStream_t stream);      // DevScene::passes -> one contiguous plane
@@ -18,5 +17,3 @@ void er_launch_debug_hit(const DevScene& S, const float* o, const float* d, uint
 void er_launch_render(const DevScene& S, uint32_t n_samples, bool count, hipStream_t stream);
 void er_launch_pack(const DevScene& S, const uint32_t* tiles, uint32_t ntiles, int pass, void* dst, hipStream_t stream);
 void er_launch_unpack(const DevScene& S, const uint32_t* tiles, uint32_t ntiles, int pass, const void* src, hipStream_t stream);
-// ring: (owned slots + 4 per wave) uint2 records, see er_fused.hip
-void er_launch_fused(const DevScene& S, void* ring, void* spill, uint32_t n_samples, bool count, uint32_t blocks, hipStream_t stream);

@@ -173,7 +173,6 @@ hipError_t er_probe_kernels(const char** which) {
     *which = "er_render_kernel";
     if ((e = hipFuncGetAttributes(&a, (const void*)er_render_kernel<false, false>)) != hipSuccess) return e;
     if ((e = er_probe_wavefront(which)) != hipSuccess) return e;
-    if ((e = er_probe_fused(which)) != hipSuccess) return e;
     if ((e = er_probe_stream(which)) != hipSuccess) return e;
     if ((e = er_probe_gpu_build(which)) != hipSuccess) return e;
     *which = nullptr;

@@ -185,7 +185,6 @@ struct ErScene {
     DevBuf<uint32_t> d_wf1;      // hit, left, occluded, 4 queues, counts
     DevBuf<uint2> d_spill;
     DevBuf<uint32_t> d_guide, d_ticket, d_deal;      // d_deal: the streaming schedule's deal of tiles to workgroups (er_stream_deal_tiles)
-    uint32_t fused_blocks = 0;
     uint32_t stream_blocks = 0, stream_tracers = 0, stream_waves = 16, stream_ring_cap = 0;     // streaming schedule (er_stream.hip): workgroups; tracer waves of the 16
     bool stream_lights = false;                         //   slot records carry the point-light query's line
     uint32_t* stream_ctl = nullptr;                     //   [0] pixel ticket, [1] status word, [2..3] tracer iterations, [4..5] busy tracer lanes of the last call, [6..7] its start, [8..23] its end per XCD (100 MHz)

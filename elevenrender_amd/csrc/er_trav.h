@@ -1,5 +1,5 @@
 // er_trav.h -- one traversal step of the 8-wide compressed BVH, shared by the wavefront trace kernel
-// (er_wavefront.hip) and the fused lane-asynchronous kernel (er_fused.hip).
+// (er_wavefront.hip) and the streaming schedule's tracer waves (er_stream.hip).
 //
 // A lane owns one ray at a time and advances it by ONE step per call sequence
 //     trav_choose  (pick the step's TRIANGLE part and/or NODE part and their addresses; pop if nothing is pending)
@@ -329,7 +329,7 @@ ERD void trav_apply_node(Trav& T, const DevScene& S, const TravStep& st, const T
     ER_MARK("apply_end");
 }
 
-// phase 3 of a lane that may do both parts in one step (wavefront, fused and the first streaming tracer): the triangle part,
+// phase 3 of a lane that may do both parts in one step (wavefront trace kernel, debug hooks): the triangle part,
 // then -- unless it ended the query -- the node part.
 template <bool COUNT>
 ERD bool trav_apply(Trav& T, const DevScene& S, const TravStep& st, const TravData& D, unsigned& c_nodes, unsigned& c_tris) {
@@ -394,7 +394,7 @@ ERD bool resolve_shadow(const DevScene& S, int* stack2, const Ray& sr, int self_
 }
 
 // ---- a whole query for ONE lane (debug hooks, er_debug.hip).  The production kernels interleave the steps of many
-// rays (er_wf_trace refills lanes, er_fused_kernel alternates with shading); the steps themselves are these. ----
+// rays (er_wf_trace and the streaming tracer waves refill lanes one by one); the steps themselves are these. ----
 template <bool COUNT>
 ERD int trav_run_closest(const DevScene& S, uint2* stack, uint2* spill, int* stack2, const Ray& ray, float limit, int& info,
                          unsigned& c_nodes, unsigned& c_tris) {

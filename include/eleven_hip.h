@@ -117,11 +117,11 @@ typedef struct ErSceneDesc {
 #define ER_FLAG_MIS          128u /* extension, default off = reference behaviour (NEE and BRDF-sampled environment both
                                      counted in full, src/kernel.cpp:571-577): balance-heuristic weights per direction */
 #define ER_FLAG_COUNTERS     2u   /* count node visits / triangle tests (slower kernel variant) */
-/* Schedule selection (every schedule computes bit-identical results).  Default: automatic, by what was measured on
- * MI355X -- the fused schedule when this rank owns fewer than 150 k pixels (launch-bound frames), the wavefront schedule
- * for more than 4 M pixels of a scene of more than 4 M triangles, the streaming schedule otherwise.  The flags force one. */
+/* Schedule selection (every schedule computes bit-identical results).  Default: the streaming schedule, at every frame size since
+ * round 5 (C1 at 256 x 256: 1 186 Msamples/s against 849 for round 1's fused kernel, which was removed), except for a rank that owns
+ * more pixels than the streaming schedule's pixel rings hold (8.4 M): the wavefront schedule.  The flags force one. */
 #define ER_FLAG_MEGAKERNEL   4u   /* v0: one wave per 8x8 tile, wave-synchronous bounce loop over the binary BVH */
-#define ER_FLAG_FUSED        16u  /* persistent waves, lane-asynchronous: trace steps + batched shading, no barrier */
+#define ER_FLAG_FUSED        16u  /* (round 1's lane-asynchronous single kernel, removed in round 5: accepted, means ER_FLAG_STREAM) */
 #define ER_FLAG_WAVEFRONT    32u  /* one trace + one shade launch per bounce over compacted ray queues */
 #define ER_FLAG_STREAM       256u /* one launch per call, one resident workgroup per CU: tracer waves and shader waves feed each
                                      other through rings in LDS (er_stream.hip) */

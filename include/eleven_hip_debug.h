@@ -34,7 +34,7 @@ int er_debug_cdf_search(const float* cdf, int length, const float* values, int32
 struct ErScene;
 int er_debug_closest_hit(struct ErScene* scene, const float* origins, const float* dirs, uint32_t n, int32_t* tri_ids, float* positions, float* distances);
 
-/* The same query through the PRODUCTION traversal -- the 8-wide interval traversal of er_wf_trace / er_fused_kernel
+/* The same query through the PRODUCTION traversal -- the 8-wide interval traversal of er_wf_trace / the streaming tracer waves
  * (csrc/er_trav.h: trav_choose / trav_fetch / trav_apply) followed by resolve_closest / resolve_shadow -- for `n`
  * arbitrary rays (directions taken as given).
  *   self_slots == NULL: closest-hit queries.  tri_ids = original triangle id (-1 miss), slots = the library's internal

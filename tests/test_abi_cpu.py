@@ -171,7 +171,7 @@ def test_shared_library_carries_gfx950_code_objects_only():
     feature suffix, which the pool's xnack- devices refuse)."""
     blob = open(abi.LIB_PATH, "rb").read()
     bundles = blob.count(b"__CLANG_OFFLOAD_BUNDLE__")
-    assert bundles >= 4, bundles            # er_kernels, er_wavefront, er_fused, er_gpu_build
+    assert bundles >= 4, bundles            # er_kernels, er_wavefront, er_stream, er_gpu_build, er_debug
     entries = re.findall(rb"hip[v0-9]*-amdgcn-amd-amdhsa-[-A-Za-z0-9_:+]*", blob)
     assert len(entries) >= bundles
     for e in entries:

@@ -32,7 +32,7 @@ def test_device_built_bvh_gives_the_same_image(kind):
         sc = scenes.torture(6000, 80, 60, seed=6, n_materials=8, tex_size=16, hdri_size=(64, 32))
     assert _accel(sc, abi.FLAG_GPU_BUILD)["builder"] == 1 and _accel(sc, abi.FLAG_HOST_BUILD)["builder"] == 0
     assert _accel(sc, 0)["builder"] == (1 if sc.tri_count >= 20000 else 0)        # the default goes by the triangle count
-    for sched in (abi.FLAG_WAVEFRONT, abi.FLAG_FUSED, abi.FLAG_MEGAKERNEL, abi.FLAG_STREAM):
+    for sched in (abi.FLAG_WAVEFRONT, abi.FLAG_MEGAKERNEL, abi.FLAG_STREAM):
         h = gpu_render(sc, 4, max_bounces=8, flags=sched | abi.FLAG_HOST_BUILD)
         d = gpu_render(sc, 4, max_bounces=8, flags=sched | abi.FLAG_GPU_BUILD)
         for p in ("beauty", "normal", "tangent", "bitangent"):

@@ -1,6 +1,6 @@
 """Function-level parity of the PRODUCTION path on the GPU (levels 1 and 2).
 
-Level 1 -- a4/a5: arbitrary rays through the 8-wide interval traversal that er_wf_trace / er_fused_kernel run
+Level 1 -- a4/a5: arbitrary rays through the 8-wide interval traversal that er_wf_trace and the streaming tracer waves run
 (csrc/er_trav.h + resolve_closest / resolve_shadow, via er_debug_trace_rays) against the oracle's throwRay
 (reference src/BVH.cpp:63-120, src/kernel.cpp:218-240).  The older test_closest_hit_function_level drives the exact
 binary-BVH routine, which production only uses as a fallback.
@@ -144,6 +144,6 @@ def test_closed_welded_mesh_image_parity_and_tie_rate(oracle_mod):
     o = oracle_render(oracle_mod, sc, 4, max_bounces=8, threads=16)
     frac = compare(g, o, min_exact=0.998, what="closed welded mesh, 131072 triangles")
     print(f"tie rate (pixels not bit-exact after 4 spp x 8 bounces): {1 - frac:.2e}")
-    for sched in (abi.FLAG_FUSED, abi.FLAG_WAVEFRONT, abi.FLAG_STREAM):
+    for sched in (abi.FLAG_WAVEFRONT, abi.FLAG_STREAM):
         f = gpu_render(sc, 4, max_bounces=8, flags=sched)
         assert (f["beauty"].view(np.uint32) == g["beauty"].view(np.uint32)).all(), sched

@@ -13,7 +13,7 @@ from test_gpu_parity import compare, gpu_render, oracle_render
 
 pytestmark = pytest.mark.gpu
 
-SCHEDULES = [abi.FLAG_WAVEFRONT, abi.FLAG_FUSED, abi.FLAG_MEGAKERNEL, abi.FLAG_STREAM]
+SCHEDULES = [abi.FLAG_WAVEFRONT, abi.FLAG_MEGAKERNEL, abi.FLAG_STREAM]
 EXT = [abi.FLAG_POINT_LIGHTS, abi.FLAG_MIS, abi.FLAG_POINT_LIGHTS | abi.FLAG_MIS]
 
 

@@ -217,7 +217,7 @@ def test_full_size_properties():
         assert a["counters"][k] == full_w["counters"][k] == full_s["counters"][k], k
     w = gpu_render(sc, 3, max_bounces=8, rank=7, world=64, flags=abi.FLAG_WAVEFRONT)
     m = gpu_render(sc, 3, max_bounces=8, rank=7, world=64, flags=abi.FLAG_MEGAKERNEL)
-    f = gpu_render(sc, 3, max_bounces=8, rank=7, world=64, flags=abi.FLAG_FUSED)
+    f = gpu_render(sc, 3, max_bounces=8, rank=7, world=64, flags=abi.FLAG_STREAM)
     assert (w["beauty"].view(np.uint32) == f["beauty"].view(np.uint32)).all()
     assert (w["beauty"].view(np.uint32) == m["beauty"].view(np.uint32)).all()
     assert w["counters"]["bounce_samples"] == m["counters"]["bounce_samples"]
@@ -229,8 +229,10 @@ def test_full_size_properties():
 
 
 @pytest.mark.parametrize("scene_kind", ["soup", "blobs", "cornell"])
-def test_fused_schedule_equals_wavefront_schedule(scene_kind):
-    """ER_FLAG_FUSED (lane-asynchronous fused kernel, no per-bounce barrier) computes the same arithmetic."""
+def test_streaming_schedule_equals_wavefront_schedule(scene_kind):
+    """The CU-resident streaming schedule (the default at every frame size) computes the same arithmetic as the launch-per-bounce
+    wavefront schedule, in one call or several; ER_FLAG_FUSED -- round 1's single kernel, removed in round 5 -- is still accepted and
+    means the streaming schedule."""
     if scene_kind == "soup":
         sc = scenes.soup(20000, 136, 100, seed=4, hdri_size=(128, 64))
     elif scene_kind == "blobs":
@@ -238,9 +240,9 @@ def test_fused_schedule_equals_wavefront_schedule(scene_kind):
     else:
         sc = scenes.cornell(100, 60)
     a = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_WAVEFRONT)
-    b = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_FUSED)
-    c = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_FUSED, chunks=[3, 4])
-    d = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_STREAM)               # ... and so does the CU-resident streaming schedule
+    b = gpu_render(sc, 7, max_bounces=8)                                      # the automatic choice: the streaming schedule
+    c = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_FUSED, chunks=[3, 4])  # (the retired flag)
+    d = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_STREAM)
     e = gpu_render(sc, 7, max_bounces=8, flags=abi.FLAG_STREAM, chunks=[2, 5])
     for p in ("beauty", "normal", "tangent", "bitangent"):
         for other in (b, c, d, e):
@@ -309,7 +311,7 @@ def _empty_scene(x_res, y_res):
     return sc
 
 
-@pytest.mark.parametrize("flags", [abi.FLAG_WAVEFRONT, abi.FLAG_FUSED, abi.FLAG_MEGAKERNEL, abi.FLAG_STREAM])
+@pytest.mark.parametrize("flags", [abi.FLAG_WAVEFRONT, abi.FLAG_MEGAKERNEL, abi.FLAG_STREAM])
 def test_edge_cases_bit_exact(oracle_mod, flags):
     """Inputs at the edges of the domain, in every schedule: no triangles at all (every ray sees the HDRI), a frame
     smaller than one tile and frames with partial tiles on both edges, zero-area and duplicated triangles (exactly
@@ -328,11 +330,11 @@ def test_edge_cases_bit_exact(oracle_mod, flags):
 
 
 def _window_schedules_agree(sc, spp, max_bounces, rank, world, mega_ties=0.0, extra_flags=0):
-    """wavefront == fused bit for bit (same traversal order); the megakernel walks the binary BVH, so on closed
+    """wavefront == streaming bit for bit (same traversal order); the megakernel walks the binary BVH, so on closed
     meshes it may resolve an exact distance tie on a shared edge the other way (`mega_ties` = tolerated pixel fraction;
     the two pixels found on C4 were checked against the oracle in both of its traversal orders: wavefront's answer)."""
     w = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_WAVEFRONT | extra_flags)
-    f = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_FUSED | extra_flags)
+    f = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=extra_flags)      # the automatic choice
     m = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_MEGAKERNEL | extra_flags)
     st = gpu_render(sc, spp, max_bounces=max_bounces, rank=rank, world=world, flags=abi.FLAG_STREAM | extra_flags)
     owned = w["samples"].reshape(w["beauty"].shape[:2]) > 1
@@ -415,7 +417,7 @@ def test_closest_hit_function_level(oracle_mod):
         orc.close()
 
 
-@pytest.mark.parametrize("flags", [abi.FLAG_WAVEFRONT, abi.FLAG_FUSED, abi.FLAG_STREAM])
+@pytest.mark.parametrize("flags", [abi.FLAG_WAVEFRONT, abi.FLAG_STREAM])
 def test_read_back_during_asynchronous_rendering_is_a_sample_boundary_snapshot(flags):
     """The reference reads passes on a second queue while the render thread enqueues samples, unsynchronised
     (src/Managers.cpp:287-302: torn reads).  Here er_read_pass is ordered after everything enqueued so far -- including

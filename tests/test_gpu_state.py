@@ -22,7 +22,7 @@ def test_resume_from_a_snapshot_equals_the_uninterrupted_render():
     snap = a.state_export()
     a.close()
     assert snap[:8].tobytes() == b"ERSTATE2" and snap.size == 64 + 88 * 60 * (5 * 16 + 8)
-    for flags in (abi.FLAG_WAVEFRONT, abi.FLAG_FUSED, abi.FLAG_MEGAKERNEL, abi.FLAG_STREAM):       # resume in any schedule
+    for flags in (abi.FLAG_WAVEFRONT, abi.FLAG_MEGAKERNEL, abi.FLAG_STREAM):       # resume in any schedule
         b = render.RenderingManager(render.RenderParameters(max_bounces=8, flags=flags))
         b.start_rendering(sc)
         b.state_import(snap)

@@ -16,8 +16,8 @@ import oracle
 from elevenrender_amd import abi, scenes
 from test_gpu_parity import gpu_render, oracle_render
 
-FLAG_SETS = (abi.FLAG_WAVEFRONT, abi.FLAG_FUSED, abi.FLAG_MEGAKERNEL, abi.FLAG_STREAM, abi.FLAG_WAVEFRONT | abi.FLAG_GPU_BUILD, abi.FLAG_FUSED | abi.FLAG_GPU_BUILD,
-             abi.FLAG_STREAM | abi.FLAG_GPU_BUILD)
+FLAG_SETS = (abi.FLAG_WAVEFRONT, abi.FLAG_MEGAKERNEL, abi.FLAG_STREAM, abi.FLAG_WAVEFRONT | abi.FLAG_GPU_BUILD, abi.FLAG_STREAM | abi.FLAG_GPU_BUILD,
+             abi.FLAG_STREAM | abi.FLAG_HOST_BUILD, abi.FLAG_WAVEFRONT | abi.FLAG_HOST_BUILD)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 bad, t0 = 0, time.time()
