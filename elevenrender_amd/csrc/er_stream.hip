@@ -561,10 +561,13 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
             // the ~1 400 instructions of accumulate + pixel ring + camera ray in nearly every shading step for a fifth of its lanes;
             // as batches of its own it runs full.  A full finish batch goes first (its slots hold no ray in flight); a partial one
             // runs when the shade ring has too little for a batch.
+            // (batch_min carries the patience in its upper bits: polls of ST_BATCH_SLEEP x 64 cycles a wave waits for a full batch before it
+            // takes a partial one; a partial finishing batch after a third of that)
+            const uint32_t bmin = batch_min & 0xFFu, patience = batch_min >> 8;
             bool fin_mode = favail >= fin_min;
-            if (!fin_mode && avail < batch_min) {
-                if (favail > 0 && (avail == 0 || spins >= 8u)) fin_mode = true;
-                else if (spins < 24u) {     // a fuller batch costs the same instructions: wait a little for one
+            if (!fin_mode && avail < bmin) {
+                if (favail > 0 && (avail == 0 || spins >= patience / 3u)) fin_mode = true;
+                else if (spins < patience) {     // a fuller batch costs the same instructions: wait a little for one
                     spins++;
                     __builtin_amdgcn_s_sleep(ST_BATCH_SLEEP);
                     continue;
@@ -936,7 +939,12 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
     static const uint32_t batch_min = [] {
         const char* e = getenv("ER_STREAM_BATCH_MIN");
         int v = e ? atoi(e) : 64;      // (five shader waves: a step that is not full is capacity lost)
-        return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
+        const char* p = getenv("ER_STREAM_BATCH_SPINS");      // patience, in polls (knob)
+        // (round 5, profiles/r05_sweep_batch_patience.log: 24 polls until now.  Waiting longer for fuller batches loses at every size --
+        // 96 polls: -2.5 % at a 1/8 share of the C2 frame, -22 % on C1; 400: -18 % / -63 % -- and waiting less costs nothing at the large
+        // sizes and wins on small frames: 3 polls +14 % on C1, +-0.3 % on the whole C2 frame and its 1/4 and 1/8 shares)
+        int sp = p ? atoi(p) : 3;
+        return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v)) | ((uint32_t)(sp < 0 ? 0 : (sp > 100000 ? 100000 : sp)) << 8);
     }();
     static const uint32_t fin_min = [] {
         const char* e = getenv("ER_STREAM_FIN_MIN");
