@@ -2,12 +2,12 @@
 """Fabric bytes per sample pass of the streaming kernel from the `fetch` and `write` passes of tools/pmc_passes.sh, merged into
 profiles/<tag>_pmc_traffic.json under the config's name (bench.py reads `roofline.traffic` from there and says "replayed").
 
-    python tools/pmc_traffic.py gpurun_out/pmc_r04_c4 r04 C4 [steps_per_pass=8]
+    python tools/pmc_traffic.py gpurun_out/pmc_r05_c4 r05 C4 [steps of the timed call = 6]
 
 bytes = 2 x FETCH_SIZE(KB) x 1024 + WRITE_SIZE(KB) x 1024 (MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE tallies 128-byte
 requests at 64 bytes; 99.8 % of these kernels' read requests are 128-byte ones, profiles/r02_pmc_request_sizes.csv).
-A pass of tools/pmc_passes.sh runs `--warmup 2 --steps 6`: the uninstrumented kernel does 8 sample passes in two launches (the
-instrumented replay is another template instance and is not counted)."""
+A pass of tools/pmc_passes.sh runs `--warmup 2 --steps 6 --repeats 1`: two launches of the uninstrumented kernel, of which the second --
+the timed call, 6 sample passes -- is counted (the instrumented replay is another template instance)."""
 import csv
 import json
 import os
@@ -15,19 +15,23 @@ import sys
 
 
 def total(path, counter, needle):
-    s, launches, ns = 0.0, set(), 0
+    """Counter sum, launch count and duration of the LAST launch of the kernel in the pass: bench.py's timed call.  (Its first launch is
+    the warm-up call, which since round 5 runs on the default deal of tiles while the kernel counts work per tile; the timed call runs on
+    the deal the library then chose -- the steady state of a render.)"""
+    per = {}
     for r in csv.DictReader(open(path)):
         if needle in r["Kernel_Name"] and r["Counter_Name"] == counter:
-            s += float(r["Counter_Value"])
-            if r["Dispatch_Id"] not in launches:
-                launches.add(r["Dispatch_Id"])
-                ns += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    return s, len(launches), ns
+            d = per.setdefault(int(r["Dispatch_Id"]), [0.0, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
+            d[0] += float(r["Counter_Value"])
+    if not per:
+        return 0.0, 0, 0
+    last = per[max(per)]
+    return last[0], len(per), last[1]
 
 
 def main():
     src, tag, config = sys.argv[1], sys.argv[2], sys.argv[3]
-    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+    steps = int(sys.argv[4]) if len(sys.argv) > 4 else 6
     needle = "er_stream_kernel<false"
     f, nf, ns_f = total(os.path.join(src, "fetch", "run_counter_collection.csv"), "FETCH_SIZE", needle)
     w, nw, ns_w = total(os.path.join(src, "write", "run_counter_collection.csv"), "WRITE_SIZE", needle)

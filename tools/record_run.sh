@@ -1,5 +1,6 @@
 #!/bin/bash
-# Record run for profiles/ (one GPU box, repo root):   bash tools/record_run.sh r05
+# Record run for profiles/ (one GPU box, repo root):   bash tools/record_run.sh r05 [bench|pmc_c2|pmc_c4|pmc_c5|all]
+# (a gpurun call lasts 20 minutes at most: the stages are run as separate calls)
 #   1. the bench line as the driver types it (C2), and rocprofv3 --kernel-trace --stats of the same command;
 #   2. the other BASELINE scenes (C4, C5, C5 without the extensions, C1), one GPU's 1/2, 1/4, 1/8 share of the C2 frame, and the
 #      two-rank rehearsal of `bench.py --gpus 2` (no launcher around it: the file starts its own ranks);
@@ -9,9 +10,11 @@
 #   python tools/pmc_table.py gpurun_out/pmc_<tag>_c2 > profiles/<tag>_pmc_c2_stream_kernel.txt, and copy the logs.
 set -eo pipefail
 tag=${1:-r05}
+stage=${2:-all}
 out=gpurun_out/record_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+if [ $stage = bench ] || [ $stage = all ]; then
 timeout -k 10 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench.log 2> $out/bench.err
 echo "bench done"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o run -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/stats.log 2>&1
@@ -28,9 +31,10 @@ for s in 2 4 8; do
 done
 ER_BENCH_REHEARSAL=1 timeout -k 10 400 python3 bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline > $out/bench_rehearsal2.log 2> $out/bench_rehearsal2.err
 echo "shares + rehearsal done"
-bash tools/pmc_passes.sh ${tag}_c2 full > $out/pmc_c2.log 2>&1
-bash tools/pmc_passes.sh ${tag}_c4 core --config C4 > $out/pmc_c4.log 2>&1
-bash tools/pmc_passes.sh ${tag}_c5 core --config C5 > $out/pmc_c5.log 2>&1
+fi
+if [ $stage = pmc_c2 ] || [ $stage = all ]; then bash tools/pmc_passes.sh ${tag}_c2 full > $out/pmc_c2.log 2>&1 || { tail -20 $out/pmc_c2.log; exit 1; }; fi
+if [ $stage = pmc_c4 ] || [ $stage = all ]; then bash tools/pmc_passes.sh ${tag}_c4 core --config C4 > $out/pmc_c4.log 2>&1 || { tail -20 $out/pmc_c4.log; exit 1; }; fi
+if [ $stage = pmc_c5 ] || [ $stage = all ]; then bash tools/pmc_passes.sh ${tag}_c5 core --config C5 > $out/pmc_c5.log 2>&1 || { tail -20 $out/pmc_c5.log; exit 1; }; fi
 echo "pmc done"
 for f in $out/bench*.log; do python3 -c "
 import json
