@@ -316,6 +316,13 @@ private:
             else if (s == "megakernel") rp.flags |= ER_FLAG_MEGAKERNEL;
             else if (s != "auto") throw std::runtime_error("config schedule '" + s + "' not recognised");
         }
+        // which builder makes the acceleration structure (the library's default: the device build from 20 000 triangles up)
+        if (const json::Value* v = j.if_contains("builder")) {
+            const std::string& s = v->as_string();
+            if (s == "host") rp.flags |= ER_FLAG_HOST_BUILD;
+            else if (s == "device") rp.flags |= ER_FLAG_GPU_BUILD;
+            else if (s != "auto") throw std::runtime_error("config builder '" + s + "' not recognised");
+        }
         // several GPUs of this node behind the one session (SURVEY.md section 5 planned `gpus` beside max_bounces; reference hook
         // src/CommandManager.cpp:154-172): "gpus": N, optionally "devices": [ordinals] and "transport": "auto" | "rccl" | "local"
         if (const json::Value* v = j.if_contains("gpus")) {
