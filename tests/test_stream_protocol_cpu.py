@@ -40,7 +40,11 @@ def model_tsan(tmp_path_factory):
 
 
 def _run(exe, *args, timeout=300):
-    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66")
+    # (ER_MODEL_DEBUG: the model prints its rings' counters once a second -- a run lasts a second or two, so this is a line or two, and
+    # if a run ever stalls the assertion's message shows where.  Round 5 saw this file fail twice on a heavily loaded box -- "put guard
+    # expired" in the 16-slot / 16-pixel case, once beside a parallel compile job, once in a suite run that took five times its usual
+    # time -- and never in ~150 repetitions of the same case alone or beside 12 busy loops: NOTEBOOK.md, round 5.)
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", ER_MODEL_DEBUG="1")
     env.pop("LD_PRELOAD", None)      # (tools/sanitize_cpu.sh preloads the ASan runtime into python: not into a TSan binary)
     return subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout, env=env)
 
