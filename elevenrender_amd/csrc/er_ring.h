@@ -52,12 +52,12 @@ ER_RING_FN unsigned long long er_ring_cas64(unsigned long long* p, unsigned long
     __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
     return expect;
 }
-// (a waiter yields; every 1024th poll of a thread it sleeps a millisecond instead, so that on an oversubscribed machine -- the CPU
+// (a waiter yields; every 8192nd poll of a thread it sleeps a millisecond instead, so that on an oversubscribed machine -- the CPU
 // suite beside a compile job -- the thread it waits for gets its core long before the poll guard expires: round 5 saw a correct run
 // of the model end in "put guard expired" under exactly that load)
 ER_RING_FN void er_ring_pause() {
     static thread_local uint32_t polls = 0;
-    if ((++polls & 1023u) == 0u) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    if ((++polls & 8191u) == 0u) std::this_thread::sleep_for(std::chrono::milliseconds(1));
     else std::this_thread::yield();
 }
 #else

@@ -137,7 +137,7 @@ struct Model {
             const int g = take(rq, LANES, e);
             if (g == 0) {
                 if (er_ring_load(&done)) break;
-                std::this_thread::yield();
+                if ((idle & 16383u) == 16383u) std::this_thread::sleep_for(std::chrono::milliseconds(1)); else std::this_thread::yield();      // (an idle wave mostly yields)
                 const uint32_t pr = er_ring_load(&rq.ctl[ER_RING_TAIL]) + er_ring_load(&sq.ctl[ER_RING_TAIL]) + er_ring_load(&fq.ctl[ER_RING_TAIL]);
                 if (pr != progress) { progress = pr; idle = 0; }
                 if (++idle > 40000000u) { err("tracer watchdog"); er_ring_store(&done, 1u); break; }
@@ -167,7 +167,7 @@ struct Model {
             if (g == 0) { fin_mode = true; g = take(fq, LANES, e); }
             if (g == 0) {
                 if (er_ring_load(&done)) break;
-                std::this_thread::yield();
+                if ((idle & 16383u) == 16383u) std::this_thread::sleep_for(std::chrono::milliseconds(1)); else std::this_thread::yield();
                 const uint32_t pr = er_ring_load(&rq.ctl[ER_RING_TAIL]) + er_ring_load(&sq.ctl[ER_RING_TAIL]) + er_ring_load(&fq.ctl[ER_RING_TAIL]);
                 if (pr != progress) { progress = pr; idle = 0; }
                 if (++idle > 40000000u) { err("shader watchdog"); er_ring_store(&done, 1u); break; }
@@ -269,7 +269,7 @@ struct Model {
                     uint32_t guard = 0;
                     while ((((uint32_t)((w = __atomic_load_n(&px_cells[cell], __ATOMIC_ACQUIRE)) >> 32)) & 0xFF000000u) != lap_tag(pos, px_cap)) {
                         if (++guard > 400000000u) { err("pixel cell guard expired"); break; }
-                        std::this_thread::yield();
+                        er_ring_pause();
                     }
                     if (variant != 2) er_bits_release(px_bits.data(), cell);
                     const uint32_t left = (uint32_t)(w >> 32) & 0x00FFFFFFu, pixel = (uint32_t)w;

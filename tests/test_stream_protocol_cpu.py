@@ -15,10 +15,12 @@ SRC = os.path.join(ROOT, "tests", "native", "ring_model.cpp")
 HDR = os.path.join(ROOT, "elevenrender_amd", "csrc", "er_ring.h")
 
 
-def _build(tmp, name, flags, guard_log2=25):
-    """guard = polls (one sched_yield each) a ring wait may last before the model calls it a protocol fault.  The checked protocol
-    never needs it, so it is long -- a thread of the model can be off its core for a while on a busy machine, and a short guard
-    once failed a correct run there.  The negative control needs a short one: its lost entries are waited for until it expires."""
+def _build(tmp, name, flags, guard_log2=31):
+    """guard = polls a ring wait may last before the model calls it a protocol fault.  The checked protocol never needs it, so the
+    model's is practically unbounded (2^31 polls, a millisecond of sleep every 8 192: minutes beyond the run's timeout): a wait that never ends is caught
+    by the run's own timeout instead, and a thread that is merely off its core for a long while on a busy machine -- which failed
+    correct runs twice in round 5 with a guard of 2^25 -- is not a fault.  The negative control needs a short guard: its lost entries
+    are waited for until it expires."""
     exe = str(tmp / name)
     subprocess.run(["g++", "-std=c++17", "-pthread", "-DER_RING_HOST_MODEL", f"-DER_RING_GUARD=(1u<<{guard_log2})"] + flags + [SRC, "-o", exe], check=True)
     return exe
