@@ -217,3 +217,28 @@ def test_transcendentals(rig):
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
         L.oracle_math(op, orc.MATH_ER, fp(x), fp(y), fp(ref), n)
         assert same(got, ref).all(), op
+
+
+def test_texture_fetch_refuses_entries_the_library_keeps_compacted(oracle_mod):
+    """With the compaction on (the default), a texture that materials use for scalar channels only lives on the device with its first
+    channel alone, possibly already to the power 2.2: a debug fetch from that entry would not be a fetch from the scene's texture, so
+    er_debug_eval(ER_FN_TEXTURE) refuses it (ER_ERR_STATE, with the way out in the message) instead of answering with other values
+    (ADVICE r4); textures that are kept as they came -- an albedo texture, the HDRI -- are still served."""
+    sc = scenes.torture(600, 48, 36, seed=9, n_materials=4, tex_size=16, hdri_size=(64, 32), smooth=True, n_lights=0)
+    rm = render.RenderingManager(render.RenderParameters(max_bounces=8))
+    rm.start_rendering(sc)
+    try:
+        rough = sc.materials[0].roughness_tex
+        albedo = sc.materials[0].albedo_tex
+        assert rough >= 0 and albedo >= 0 and rough != albedo
+        def item(tid):
+            row = np.array([[0.0, 0.3, 0.6, 0.0]], np.float32)
+            row.view(np.int32)[0, 0] = tid          # (the id travels as float BITS)
+            return row
+        with pytest.raises(abi.ErError) as e:
+            rm.debug_eval(FN["TEXTURE"], item(rough), 3)
+        assert e.value.code == abi.ER_ERR_STATE and "ER_TEX_COMPACT=0" in str(e.value)
+        assert np.isfinite(rm.debug_eval(FN["TEXTURE"], item(albedo), 3)).all()
+        assert np.isfinite(rm.debug_eval(FN["TEXTURE"], item(-1), 3)).all()
+    finally:
+        rm.close()
