@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 knob sweeps on the GPU box (one process at a time, each under its own timeout; stops at the first failure).
-#   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU, fused schedule
+#   bash tools/sweep_r04.sh sim8   -> one GPU's 1/8 share of the C2 frame: tracer/shader split at 16, 12 and 8 waves per CU
 #   bash tools/sweep_r04.sh c4     -> C4: tracer/shader split, ring-visit and batch thresholds
 set -o pipefail
 what=${1:?sim8|c4|c4w|shares|knobs|retune|knobs13|diet|supertile|supertile2|supertile3|level|edgeauto|sharesedge|texcompact}
@@ -22,7 +22,6 @@ if [ "$what" = sim8 ]; then
   for t in 6 8 10 11 12 13; do run w16_t$t ER_STREAM_TRACERS=$t -- $S; done
   for t in 6 8 9 10; do run w12_t$t ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_w12.so ER_STREAM_TRACERS=$t -- $S; done
   for t in 4 5 6; do run w8_t$t ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_w8.so ER_STREAM_TRACERS=$t -- $S; done
-  run fused X=1 -- $S --schedule fused
   run w16_t12_batch16 ER_STREAM_TRACERS=12 ER_STREAM_BATCH_MIN=16 ER_STREAM_FIN_MIN=16 -- $S
   run w12_t9_batch16 ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_w12.so ER_STREAM_TRACERS=9 ER_STREAM_BATCH_MIN=16 ER_STREAM_FIN_MIN=16 -- $S
 elif [ "$what" = c4 ]; then
