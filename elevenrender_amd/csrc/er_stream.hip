@@ -66,6 +66,18 @@ using namespace erd;
 #define ER_TPS(n) ((void)0)
 #endif
 
+// Diagnostic build (-DER_STAGE_PROBE, tools/stage_probe.py): where does a bounce of a path spend its time?  Every closest-hit ray is
+// stamped (wall_clock64, 10-ns ticks) when a shader wave queues it (A), when a tracer lane takes it (B), when its traversal ends (C),
+// when the tracer publishes it (D), when a shader wave starts the slot's next step (E) and when that step has queued the next ray (F);
+// the sums of B-A, C-B, D-C, E-D, F-E and the number of rays come back in the event counters (meaningless otherwise in this build).
+#ifdef ER_STAGE_PROBE
+#define ER_SP(x) x
+__device__ __forceinline__ uint32_t sp_now() { return (uint32_t)wall_clock64(); }
+__device__ __forceinline__ void sp_add(unsigned long long* c, uint32_t d) { atomicAdd(c, (unsigned long long)d); }
+#else
+#define ER_SP(x)
+#endif
+
 namespace {
 
 #define ST_SLOT_BITS 11          // ring payloads: local slot (11 bits) | kind or flag (2 bits) = ER_RING_PAYLOAD_BITS
@@ -211,6 +223,8 @@ struct StState {
     __device__ __forceinline__ int& occ_b(uint32_t i) const { return fld2<int, 80, 296>(i); }
     __device__ __forceinline__ uint32_t& left(uint32_t i) const { return fld<uint32_t, 84>(i); }
     __device__ __forceinline__ uint32_t& pix(uint32_t i) const { return fld<uint32_t, 88>(i); }
+    __device__ __forceinline__ uint32_t& stamp(uint32_t i) const { return fld<uint32_t, 92>(i); }      // (ER_STAGE_PROBE only: 10-ns ticks)
+    __device__ __forceinline__ uint32_t& stamp0(uint32_t i) const { return fld<uint32_t, 208>(i); }    // (... when the slot's sample began)
     __device__ __forceinline__ float4& light(uint32_t i) const { return fld<float4, 96>(i); }
     __device__ __forceinline__ float4& reduc(uint32_t i) const { return fld<float4, 112>(i); }
     __device__ __forceinline__ float4& aov_n(uint32_t i) const { return fld<float4, 128>(i); }
@@ -264,6 +278,7 @@ __device__ __forceinline__ void st_begin_sample(const DevScene& S, const StState
     W.aov_t(g) = make_float4(0, 0, 0, 0);
     W.aov_b(g) = make_float4(0, 0, 0, 0);
     W.left(g) = left;
+    ER_SP(W.stamp(g) = sp_now(); W.stamp0(g) = W.stamp(g);)
 }
 
 // what a finished traversal leaves in the slot's record (closest: winner + second candidate; shadow: verdict + candidates)
@@ -378,6 +393,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                                    // record index g0 + slot (+ W.slots for a point-light query) is recomputed where it is needed)
             uint32_t idle = 0, progress = 0;
             uint32_t a_iter = 0, a_busy = 0;      // iterations of this wave's loop and the lanes that held a ray in them (-> status[1..4])
+            ER_SP(uint32_t spA = 0; uint32_t spB = 0; uint32_t spC = 0; uint32_t sAB = 0; uint32_t sBC = 0; uint32_t sCD = 0; uint32_t sN = 0;)      // (per lane, flushed once at the end)
             while (true) {
                 ER_MARK("tracer_loop_top");
                 // Every refill_min idle lanes the wave does its ring work in one go: FIRST the finished rays of the idle lanes are
@@ -392,6 +408,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                     ER_MARK("tracer_publish");
                     const uint32_t ls = lsk & ST_SLOT_MASK, kind = lsk >> ST_SLOT_BITS;
                     if (done) st_write_result(W, g0 + ls + (kind == 2u ? W.slots : 0u), T.shadow, done_occl, T.overflow, T.s0, T.s1);
+                    ER_SP(if (done && kind == 0u) { const uint32_t spD = sp_now(); sAB += spB - spA; sBC += spC - spB; sCD += spD - spC; sN++; W.stamp(g0 + ls) = spD; })
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     bool last = false;
                     uint32_t fin = 0;
@@ -434,6 +451,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                                        shadow ? rd.w : __builtin_inff());
                             c_rays++;
                             busy = true;
+                            ER_SP(if (kind == 0u) { spA = W.stamp(rec); spB = sp_now(); })
                         }
                     }
                 }
@@ -495,7 +513,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 }
                 if (busy) {
                     if (do_step && occl) finished = true;
-                    if (finished) { busy = false; done = true; done_occl = occl; }
+                    if (finished) { busy = false; done = true; done_occl = occl; ER_SP(spC = sp_now();) }
                 }
 #else
                 {
@@ -517,6 +535,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 ER_MARK("tracer_iter_end");
             }
             ER_MARK("tracer_loop_end");
+            ER_SP({ unsigned long long* spc = (unsigned long long*)&S.counters->node_visits; sp_add(spc + 0, sAB); sp_add(spc + 1, sBC); sp_add(spc + 2, sCD); sp_add(spc + 5, sN); })
             // how full the tracer lanes were: the host reads it after the call and moves one wave between the two roles for the next
             // call when the tracers starve or the shaders idle (er_api.cpp, er_stream_adapt)
             if (lane == 0) {
@@ -532,6 +551,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
         bool have = false;
         uint32_t e = 0;
         uint32_t idle = 0, spins = 0, progress = 0;
+        ER_SP(uint32_t sDE = 0; uint32_t sEF = 0; uint32_t sGE = 0; uint32_t sNG = 0; uint32_t sSS = 0; uint32_t sNS = 0;)
 #if ER_SHADER_PRIO
         __builtin_amdgcn_s_setprio(ER_SHADER_PRIO);      // (static priority for the whole loop: issue arbitration is by priority, then age)
 #endif
@@ -589,6 +609,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
             uint32_t rs = 0, left_after = 0, done_idx = 0;
             ER_MARK("shader_step");
             ER_TPS(1);
+            ER_SP(uint32_t spE = 0;)
+            ER_SP(if (have) { spE = sp_now(); if (fin_mode ? (e >> ST_SLOT_BITS) != 0 : (e >> ST_SLOT_BITS) == 0) sDE += spE - W.stamp(slot);
+                              else if (fin_mode) { sGE += spE - W.stamp(slot); sNG++; } })
             if (have && !fin_mode) {
                 const bool fin_only = (e >> ST_SLOT_BITS) != 0;
                 float4 L4 = W.light(slot), R4 = W.reduc(slot);
@@ -666,6 +689,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                     W.light(slot) = make_float4(light.x, light.y, light.z, __builtin_bit_cast(float, rs));
                     alive = false;
                     to_finish = true;
+                    ER_SP(W.stamp(slot) = sp_now();)      // G: handed to the finish ring by a shading step
                 } else {
                     push_closest = true;
                 }
@@ -738,6 +762,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 if (sa2 != sa) S.samples[idx] = sa2;
                 S.rng[idx] = rs;
                 c_paths++;
+                ER_SP(sSS += sp_now() - W.stamp0(slot); sNS++;)
                 // the sample is done: the pixel goes back to the ring (below, as a wave) and the slot takes the next one
                 left_after = W.left(slot) - 1;
                 done_idx = pxy;
@@ -806,6 +831,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
             {
                 const unsigned long long mc = __ballot(push_closest), ms = __ballot(push_shadow), ml = EXT ? __ballot(push_light) : 0ull;
                 const unsigned nc = (unsigned)__popcll(mc), ns = (unsigned)__popcll(ms), nl = (unsigned)__popcll(ml);
+                ER_SP(if (push_closest) { const uint32_t spF = sp_now(); sEF += spF - spE; W.stamp(slot) = spF; })
                 if (nc + ns + nl) {
                     uint32_t base = 0;
                     if (lane == 0) base = er_ring_reserve(s_rq_ctl, nc + ns + nl);
@@ -833,8 +859,12 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
 #endif
         }
         ER_MARK("shader_loop_end");
+        ER_SP({ unsigned long long* spc = (unsigned long long*)&S.counters->node_visits; sp_add(spc + 3, sDE); sp_add(spc + 4, sEF); sp_add(spc + 6, sGE); sp_add(spc + 7, sNG); sp_add(spc + 8, sSS); atomicAdd(&S.counters->paths, (unsigned long long)sNS); })
     }
     ER_MARK("epilogue");
+#ifdef ER_STAGE_PROBE
+    return;
+#endif
 #ifdef ER_TIME_PROBE
     __syncthreads();
     if (threadIdx.x == 0) {
