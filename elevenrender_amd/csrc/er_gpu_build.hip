@@ -794,6 +794,7 @@ hipError_t er_probe_gpu_build(const char** which) {   // see er_kernels.h
 int er_gpu_build_device(const ErGpuSceneArrays& a, uint32_t n, int device, ErGpuBvhDevice* out, std::string& err) {
     auto t0 = std::chrono::steady_clock::now();
     if (n <= ER_BVH_LEAF_MAX) { err = "too few triangles for the device builder"; return 1; }
+    if (getenv("ER_DEBUG_GPU_BUILD_FAIL")) { err = "simulated failure (ER_DEBUG_GPU_BUILD_FAIL)"; return -1; }      // (test knob: the caller's fallback to the host build)
     GpuBuild B;
     int rc = B.binary(a.vertices, a.normals, n, device, err);
     if (rc != 0) return rc;
