@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/eleven_hip_debug.h"
+#include "er_bvh.h"
 
 struct DevScene;
 
@@ -13,7 +14,9 @@ struct DevScene;
 void er_launch_debug_trace(const DevScene& S, const float* o, const float* d, uint32_t n, const int32_t* self, const float* limit,
                            int32_t* tri, int32_t* slot, float* pos, float* dist, int32_t* info, void* spill, hipStream_t stream);
 // ONE more sample of pixel idx, one record per executed bounce-loop iteration.  spill: ER_DEBUG_PIXEL_SCRATCH uint2.
-#define ER_DEBUG_PIXEL_SCRATCH ((32 + 8 + 16) * 64)   /* spill levels + LDS-stack levels + the exact routine's int stack */
+// (derived from the depth bound: the traversal's spill levels occupy entries [0, ER_BVH_MAX_DEPTH x 64), the exact routine's int stack
+// -- ER_BVH_MAX_DEPTH levels x 64 ints = half as many uint2 -- follows them; er_debug.hip asserts the two agree)
+#define ER_DEBUG_PIXEL_SCRATCH ((ER_BVH_MAX_DEPTH + ER_BVH_MAX_DEPTH / 2) * 64)
 void er_launch_debug_pixel(const DevScene& S, uint32_t idx, ErTraceRec* recs, int max_recs, int* count, void* spill, hipStream_t stream);
 // device functions of the path, one item per thread (ER_FN_* of include/eleven_hip_debug.h)
 void er_launch_debug_eval(const DevScene& S, int kind, const float* in, uint32_t n, uint32_t in_stride, float* out, uint32_t out_stride, hipStream_t stream);

@@ -63,6 +63,8 @@ __global__ __launch_bounds__(64) void er_debug_pixel_kernel(DevScene S, uint32_t
     __shared__ uint2 sh_stack[WF_LDS_STACK * 64];
     uint2* s_stack = sh_stack;
     int* s_stack2 = (int*)(spill + (size_t)ER_STACK * 64);
+    static_assert((size_t)ER_STACK * 64 + ((size_t)ER_STACK * 64 * sizeof(int) + sizeof(uint2) - 1) / sizeof(uint2) <= (size_t)ER_DEBUG_PIXEL_SCRATCH,
+                  "er_debug_trace_pixel's scratch must hold the spill levels and the exact routine's int stack");
     if (threadIdx.x != 0) return;
     int nrec = 0;
     unsigned c_rays = 0, c_nodes = 0, c_tris = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;

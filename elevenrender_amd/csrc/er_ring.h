@@ -60,6 +60,30 @@ ER_RING_FN void er_ring_pause() {
     if ((++polls & 8191u) == 0u) std::this_thread::sleep_for(std::chrono::milliseconds(1));
     else std::this_thread::yield();
 }
+// What this thread is waiting for, readable by the thread that dumps the model's state when a guard expires (round 6): a wait that
+// outlasts the guard must explain itself -- "a reader that was off its core" and "a wait cycle" look alike from one line of text,
+// and different in (ring, position, the cell's word, who else waits for what).
+struct ErRingWait {
+    const char* what = nullptr;            // "put" / "get" / "bits" / ... ; nullptr = not waiting
+    const void* cells = nullptr;           // which ring (its cell array)
+    uint32_t pos = 0, seen = 0;            // the position waited for; the cell's word at the last poll
+    std::chrono::steady_clock::time_point since;
+};
+inline thread_local ErRingWait er_ring_waiting;
+#ifndef ER_RING_GUARD_MS
+#define ER_RING_GUARD_MS 120000            // the host model's guard is wall-clock time: a poll count measures the machine's load, not the protocol
+#endif
+ER_RING_FN void er_ring_wait_begin(const char* what, const void* cells, uint32_t pos) {
+    er_ring_waiting.cells = cells; er_ring_waiting.pos = pos; er_ring_waiting.seen = 0;
+    er_ring_waiting.since = std::chrono::steady_clock::now();
+    __atomic_store_n(&er_ring_waiting.what, what, __ATOMIC_RELEASE);
+}
+ER_RING_FN void er_ring_wait_end() { __atomic_store_n(&er_ring_waiting.what, (const char*)nullptr, __ATOMIC_RELEASE); }
+ER_RING_FN bool er_ring_expired(uint32_t& guard, uint32_t seen) {
+    __atomic_store_n(&er_ring_waiting.seen, seen, __ATOMIC_RELAXED);
+    if ((++guard & 1023u) != 0u) return false;
+    return std::chrono::steady_clock::now() - er_ring_waiting.since > std::chrono::milliseconds(ER_RING_GUARD_MS);
+}
 #else
 #include <hip/hip_runtime.h>
 #define ER_RING_FN __device__ __forceinline__
@@ -79,6 +103,8 @@ ER_RING_FN unsigned long long er_ring_load64(const unsigned long long* p) { retu
 ER_RING_FN unsigned long long er_ring_add64(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 ER_RING_FN unsigned long long er_ring_cas64(unsigned long long* p, unsigned long long expect, unsigned long long desired) { return atomicCAS(p, expect, desired); }
 ER_RING_FN void er_ring_pause() { __builtin_amdgcn_s_sleep(1); }
+ER_RING_FN void er_ring_wait_begin(const char*, const void*, uint32_t) {}
+ER_RING_FN void er_ring_wait_end() {}
 #endif
 
 #define ER_RING_PAYLOAD_BITS 13
@@ -94,6 +120,9 @@ enum { ER_RING_TAIL = 0, ER_RING_COUNT = 2, ER_RING_HEAD = 3, ER_RING_WORDS = 4 
 #ifndef ER_RING_GUARD
 #define ER_RING_GUARD (1u << 22)
 #endif
+#ifndef ER_RING_HOST_MODEL
+ER_RING_FN bool er_ring_expired(uint32_t& guard, uint32_t) { return ++guard >= ER_RING_GUARD; }
+#endif
 
 ER_RING_FN uint32_t er_ring_lap(uint32_t pos, uint32_t cap_log2) { return (pos >> cap_log2) << ER_RING_LAP_SHIFT; }
 
@@ -102,10 +131,14 @@ ER_RING_FN uint32_t er_ring_lap(uint32_t pos, uint32_t cap_log2) { return (pos >
 ER_RING_FN bool er_ring_put(uint32_t* cells, uint32_t cap_log2, uint32_t pos, uint32_t payload) {
     uint32_t* cell = cells + (pos & ((1u << cap_log2) - 1u));
     const uint32_t empty = er_ring_lap(pos, cap_log2);
-    uint32_t guard = 0;
-    while (er_ring_load(cell) != empty) {        // the previous lap's entry is still being read
-        if (++guard >= ER_RING_GUARD) return false;
-        er_ring_pause();
+    uint32_t guard = 0, v;
+    if ((v = er_ring_load(cell)) != empty) {     // the previous lap's entry is still being read
+        er_ring_wait_begin("put: the previous lap's reader of the cell", cells, pos);
+        do {
+            if (er_ring_expired(guard, v)) return false;      // (the wait word stays: the dump shows what was waited for)
+            er_ring_pause();
+        } while ((v = er_ring_load(cell)) != empty);
+        er_ring_wait_end();
     }
     er_ring_store(cell, empty | ER_RING_FULL | (payload & ER_RING_PAYLOAD_MASK));
     return true;
@@ -115,9 +148,13 @@ ER_RING_FN bool er_ring_get(uint32_t* cells, uint32_t cap_log2, uint32_t pos, ui
     uint32_t* cell = cells + (pos & ((1u << cap_log2) - 1u));
     const uint32_t full = er_ring_lap(pos, cap_log2) | ER_RING_FULL;
     uint32_t v, guard = 0;
-    while (((v = er_ring_load(cell)) & ~ER_RING_PAYLOAD_MASK) != full) {      // its writer is on its way
-        if (++guard >= ER_RING_GUARD) { payload = 0; return false; }
-        er_ring_pause();
+    if (((v = er_ring_load(cell)) & ~ER_RING_PAYLOAD_MASK) != full) {         // its writer is on its way
+        er_ring_wait_begin("get: the writer of the cell", cells, pos);
+        do {
+            if (er_ring_expired(guard, v)) { payload = 0; return false; }
+            er_ring_pause();
+        } while (((v = er_ring_load(cell)) & ~ER_RING_PAYLOAD_MASK) != full);
+        er_ring_wait_end();
     }
     payload = v & ER_RING_PAYLOAD_MASK;
     er_ring_store(cell, er_ring_lap(pos + (1u << cap_log2), cap_log2));        // (lap + 1, empty): free for the next lap's writer
@@ -154,9 +191,13 @@ ER_RING_FN uint32_t er_ring_grant(uint32_t* ctl, uint32_t want, uint32_t& base) 
 ER_RING_FN bool er_bits_acquire(uint32_t* bits, uint32_t idx) {
     const uint32_t m = 1u << (idx & 31u);
     uint32_t guard = 0;
-    while (er_ring_or(&bits[idx >> 5], m) & m) {
-        if (++guard >= ER_RING_GUARD) return false;
-        er_ring_pause();
+    if (er_ring_or(&bits[idx >> 5], m) & m) {
+        er_ring_wait_begin("bits: the previous lap's reader of the pixel cell", bits, idx);
+        do {
+            if (er_ring_expired(guard, m)) return false;
+            er_ring_pause();
+        } while (er_ring_or(&bits[idx >> 5], m) & m);
+        er_ring_wait_end();
     }
     return true;
 }

@@ -94,12 +94,16 @@ static_assert(ER_STREAM_SLOTS <= (1u << ST_SLOT_BITS) && ST_SLOT_BITS + 2 <= ER_
 // ring capacities (log2).  With the checked cells a full ring only makes its producers wait (shader waves for the tracers
 // to drain the ray ring -- which they do whatever the shaders are doing -- never the other way round: the shade ring holds
 // a slot at most once, so ER_STREAM_SLOTS cells can never be full), so capacities are a tuning matter, not a safety margin.
-#define ST_RQ_LOG2 12u
+#define ST_RQ_LOG2 (ER_STREAM_SLOTS > 1024u ? 13u : 12u)
 #define ST_SQ_LOG2 (ER_STREAM_SLOTS > 1024u ? 11u : 10u)
 static_assert((1u << ST_SQ_LOG2) >= ER_STREAM_SLOTS, "the shade ring must hold every slot once");
 // a wave's reservation (<= 3 x 64 entries) must fit the ring several times over (a reservation longer than the ring would wait for
 // readers of its own unpublished entries), and the camera rays of all slots go in before the waves start
 static_assert((1u << ST_RQ_LOG2) >= ER_STREAM_SLOTS && (1u << ST_RQ_LOG2) >= 4u * 192u, "ray ring too small");
+// ... and every ray the slots can have in flight at once -- a closest-hit ray and an HDRI shadow query per slot, a point-light query
+// as well with the extension (asserted for that case: one ring size serves both) -- so that the ray ring is never full either and NO
+// producer of this kernel ever waits for a reader (the model, tests/native/ring_model.cpp, runs far below this on purpose)
+static_assert((1u << ST_RQ_LOG2) >= 3u * ER_STREAM_SLOTS, "the ray ring must hold three rays per slot");
 // Static issue priority (s_setprio once, before the loop: arbitration between the waves of a SIMD is by priority, then age).  A
 // shading step is ~6 000 vector instructions on a SIMD it shares with two or three tracer waves and was 138 k cycles long
 // (profiles/r03_shader_sections_c2.log); with the shader waves at priority 1 five of them fed eleven tracer waves (four feed twelve

@@ -14,6 +14,12 @@
 //     variant 0  the protocol of the kernel
 //     variant 2  the same, but producers do NOT wait for the previous lap's reader (the protocol of round 2: plain overwrite) --
 //                a negative control: with small rings this loses rays or reads the wrong lap, and the model says so
+//     variant 3  the kernel's protocol with the model's ONE start-up precondition switched off: a ray ring with fewer cells than a
+//                wave's reservation.  That is a REAL wait cycle (the producer's third put waits for the reader of its own first
+//                entry, which cannot be granted before the producer publishes): the run ends in the guard and prints the state
+//                dump -- what a cycle looks like, as opposed to a reader that was merely off its core.
+//   On the first expired guard (wall clock, ER_RING_GUARD_MS) the model dumps, once: every ring's TAIL / COUNT / HEAD, and for every
+//   thread its role and what it is waiting for (ring, position, the cell's word as last seen and the lap that position needs).
 //   ring_model script
 //     the SAME negative control as ONE scripted interleaving on one thread (no timing in it): a reader is granted a position and
 //     stalls before reading its cell; the ring comes round; the checked producer of er_ring.h refuses to touch the cell until the
@@ -24,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -68,9 +75,58 @@ struct Model {
     uint32_t px_cap = 0;
     uint32_t live = 0, done = 0;
     std::atomic<uint32_t> errors{0}, rays_traced{0}, rays_pushed{0}, shortcuts{0};
+    // every model thread registers its wait word (er_ring.h) and its role: the state dump reads them
+    struct ThreadInfo { const char* role; uint32_t id; const ErRingWait* wait; };
+    std::mutex reg_mtx;
+    std::vector<ThreadInfo> threads;
+    std::atomic<bool> dumped{false};
+    void reg(const char* role, uint32_t id) {
+        std::lock_guard<std::mutex> lk(reg_mtx);
+        threads.push_back({role, id, &er_ring_waiting});
+    }
+    const char* ring_name(const void* cells, uint32_t& log2) const {
+        log2 = 0;
+        if (cells == rq.cells.data()) { log2 = rq.log2; return "ray ring"; }
+        if (cells == sq.cells.data()) { log2 = sq.log2; return "shade ring"; }
+        if (cells == fq.cells.data()) { log2 = fq.log2; return "finish ring"; }
+        if (cells == px_bits.data()) return "pixel ring bits";
+        if (cells == px_cells.data()) return "pixel ring cell";
+        return "?";
+    }
+    // ONE dump per run, by the first thread whose guard expires: enough to tell a descheduled reader (everybody else idle or done, the
+    // waited cell one step from the state the waiter needs, its reader / writer not waiting for anything) from a wait cycle
+    // (threads waiting for each other's positions, COUNT 0 with TAIL - HEAD > 0).
+    void dump_state(const char* why) {
+        if (dumped.exchange(true)) return;
+        std::lock_guard<std::mutex> lk(reg_mtx);
+        fprintf(stderr, "==== ring model state dump (%s) ====\n", why);
+        auto d = [&](const char* n, Ring& r) {
+            fprintf(stderr, "  %-11s cap %4u  TAIL %u  COUNT %u  HEAD %u  (reserved and not yet granted: %u)\n", n, 1u << r.log2, er_ring_load(&r.ctl[ER_RING_TAIL]),
+                    er_ring_load(&r.ctl[ER_RING_COUNT]), er_ring_load(&r.ctl[ER_RING_HEAD]), er_ring_load(&r.ctl[ER_RING_TAIL]) - er_ring_load(&r.ctl[ER_RING_HEAD]));
+        };
+        d("ray ring", rq); d("shade ring", sq); d("finish ring", fq);
+        fprintf(stderr, "  %-11s cap %4u  TAIL %u  COUNT %u  HEAD %u\n", "pixel ring", px_cap, er_ring_load(&px.ctl[ER_RING_TAIL]), er_ring_load(&px.ctl[ER_RING_COUNT]), er_ring_load(&px.ctl[ER_RING_HEAD]));
+        fprintf(stderr, "  live slots %u, done %u\n", er_ring_load(&live), er_ring_load(&done));
+        const auto now = std::chrono::steady_clock::now();
+        for (const ThreadInfo& t : threads) {
+            const char* what = __atomic_load_n(&t.wait->what, __ATOMIC_ACQUIRE);
+            if (!what) { fprintf(stderr, "  %s %u: not waiting on a ring cell\n", t.role, t.id); continue; }
+            uint32_t log2 = 0;
+            const char* rn = ring_name(t.wait->cells, log2);
+            const uint32_t pos = t.wait->pos, seen = __atomic_load_n(&t.wait->seen, __ATOMIC_RELAXED);
+            const double ms = std::chrono::duration<double, std::milli>(now - t.wait->since).count();
+            if (log2 || t.wait->cells == rq.cells.data())
+                fprintf(stderr, "  %s %u: WAITING %.0f ms in %s, %s position %u (cell %u, needs lap %u); cell word last seen: lap %u %s payload %u\n", t.role, t.id, ms, what, rn, pos,
+                        pos & ((1u << log2) - 1u), pos >> log2, seen >> ER_RING_LAP_SHIFT, (seen & ER_RING_FULL) ? "FULL" : "empty", seen & ER_RING_PAYLOAD_MASK);
+            else
+                fprintf(stderr, "  %s %u: WAITING %.0f ms in %s, %s index %u\n", t.role, t.id, ms, what, rn, pos);
+        }
+        fprintf(stderr, "==== end of dump ====\n");
+    }
 
     void err(const char* what) {
         if (errors.fetch_add(1) < 10) fprintf(stderr, "model error: %s\n", what);
+        if (strstr(what, "guard expired")) { dump_state(what); er_ring_store(&done, 1u); }      // (the run ends: the other threads leave at their next poll or at their own guard)
     }
     static uint32_t lap_tag(uint32_t pos, uint32_t cap) { return ((((pos / cap) & 0x7Fu) + 1u) << 24); }
     uint32_t path_len(uint32_t pixel, uint32_t sample) const { return 1u + hash32(pixel * 977u + sample * 131u + 7u) % 5u; }
@@ -130,7 +186,8 @@ struct Model {
         }
     }
 
-    void first_tracer() {
+    void first_tracer(uint32_t id) {
+        reg("tracer", id);
         uint32_t progress = 0, idle = 0;
         while (true) {
             uint32_t e[LANES];
@@ -156,7 +213,8 @@ struct Model {
         }
     }
 
-    void shader() {
+    void shader(uint32_t id) {
+        reg("shader", id);
         uint32_t progress = 0, idle = 0;
         while (true) {
             // a full finishing batch first, else a shading batch, else whatever the finish ring holds (er_stream.hip's shader loop)
@@ -267,10 +325,12 @@ struct Model {
                     const uint32_t pos = base + (uint32_t)i, cell = pos & (px_cap - 1u);
                     uint64_t w;
                     uint32_t guard = 0;
+                    er_ring_wait_begin("take: the writer of the pixel cell", px_cells.data(), pos);
                     while ((((uint32_t)((w = __atomic_load_n(&px_cells[cell], __ATOMIC_ACQUIRE)) >> 32)) & 0xFF000000u) != lap_tag(pos, px_cap)) {
-                        if (++guard > 400000000u) { err("pixel cell guard expired"); break; }
+                        if (er_ring_expired(guard, (uint32_t)(w >> 32))) { err("pixel cell guard expired"); break; }
                         er_ring_pause();
                     }
+                    er_ring_wait_end();
                     if (variant != 2) er_bits_release(px_bits.data(), cell);
                     const uint32_t left = (uint32_t)(w >> 32) & 0x00FFFFFFu, pixel = (uint32_t)w;
                     if (pixel >= n_pixels || left == 0) { err("garbage pixel-ring entry"); retire++; continue; }
@@ -313,8 +373,9 @@ struct Model {
         for (uint32_t s = 0; s < in_slots; s++) { begin_sample(s, s, n_samples); first.push_back(s); }
         rays_pushed.fetch_add(in_slots);
         std::vector<std::thread> th;
-        for (uint32_t t = 0; t < tracers; t++) th.emplace_back([this] { first_tracer(); });
-        for (uint32_t t = 0; t < shaders; t++) th.emplace_back([this] { shader(); });
+        reg("main (camera rays)", 0);
+        for (uint32_t t = 0; t < tracers; t++) th.emplace_back([this, t] { first_tracer(t); });
+        for (uint32_t t = 0; t < shaders; t++) th.emplace_back([this, t] { shader(t); });
         // (the camera rays go in while the waves already run: the model's ray ring may be smaller than the slots, the kernel's is
         // not -- static_assert in er_stream.hip -- and fills it before its waves start)
         for (size_t o = 0; o < first.size(); o += LANES) push(rq, first.data() + o, (int)(first.size() - o < (size_t)LANES ? first.size() - o : LANES));
@@ -414,6 +475,17 @@ int main(int argc, char** argv) {
     m.variant = argc > 4 ? (uint32_t)atoi(argv[4]) : 0;
     const uint32_t tracers = argc > 5 ? (uint32_t)atoi(argv[5]) : 3, shaders = argc > 6 ? (uint32_t)atoi(argv[6]) : 2;
     const uint32_t rq_log2 = argc > 7 ? (uint32_t)atoi(argv[7]) : 3;
-    if (m.n_slots > (1u << SLOT_BITS) || m.n_slots == 0 || m.n_pixels == 0 || (m.variant != 0 && m.variant != 2)) return 2;
+    if (m.n_slots > (1u << SLOT_BITS) || m.n_slots == 0 || m.n_pixels == 0 || (m.variant != 0 && m.variant != 2 && m.variant != 3)) return 2;
+    // Start-up preconditions (the kernel's are static_asserts in er_stream.hip):
+    //  * a wave's reservation must fit the ray ring -- else its later puts wait for readers of its own unpublished entries: a cycle.
+    //    The model REFUSES such a configuration unless asked for it on purpose (variant 3);
+    //  * the kernel's ray ring also holds every ray its slots can have in flight (2 per slot, 3 with the light extension), so that
+    //    its producers never wait at all.  The model runs BELOW that on purpose -- small rings are what makes producers wait and
+    //    positions come round -- and says so.
+    const bool fits = (1u << rq_log2) >= (uint32_t)LANES;
+    fprintf(stderr, "model: ray ring of %u cells, reservations of up to %d: %s; %u slots x 3 rays %s the ring (the kernel asserts they do: its producers never wait)\n",
+            1u << rq_log2, LANES, fits ? "fit" : "DO NOT FIT (a wait cycle)", m.n_slots, (1u << rq_log2) >= 3u * m.n_slots ? "fit" : "do not fit");
+    if (!fits && m.variant != 3) { fprintf(stderr, "model: refused (variant 3 runs it on purpose)\n"); return 2; }
+    if (m.variant == 3) m.variant = 0;
     return m.run(tracers, shaders, rq_log2);
 }

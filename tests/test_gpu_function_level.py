@@ -147,3 +147,42 @@ def test_closed_welded_mesh_image_parity_and_tie_rate(oracle_mod):
     for sched in (abi.FLAG_WAVEFRONT, abi.FLAG_STREAM):
         f = gpu_render(sc, 4, max_bounces=8, flags=sched)
         assert (f["beauty"].view(np.uint32) == g["beauty"].view(np.uint32)).all(), sched
+
+
+def test_pixel_trace_through_the_exact_re_trace(oracle_mod):
+    """ADVICE r5: er_debug_trace_pixel's scratch (spill levels + the exact routine's int stack) is derived from ER_BVH_MAX_DEPTH;
+    until round 6 the int stack began past the end of the allocation.  Every triangle three times over puts three candidates
+    into one t-interval on every hit, so every closest-hit query of the pixel trace takes the exact re-trace (trace_cold) and
+    writes that stack.  The three copies have the same Hit.position bits, so positions compare with the oracle whatever copy wins."""
+    base = scenes.soup(1500, 48, 36, seed=31, hdri_size=(64, 32))
+    rep = lambda a: np.concatenate([a, a, a], axis=0)
+    sc = abi.SceneData(rep(base.vertices), rep(base.normals), rep(base.tangents), rep(base.uvs), rep(base.tangent_sign), rep(base.material_id),
+                       base.materials, hdri=base.hdri, camera=base.camera, x_res=48, y_res=36)
+    orc = oracle_mod.Oracle(sc, math_mode=oracle_mod.MATH_ER, max_bounces=8, threads=1)
+    rm = render.RenderingManager(render.RenderParameters(max_bounces=8))
+    rm.start_rendering(sc)
+    rng = np.random.default_rng(3)
+    o, d = camera_like_rays(rng, 4000)
+    tri, slot, pos, dist, info = rm.debug_trace_rays(o, d)
+    otri, opos = orc.closest_hit(o, d)
+    hit = tri >= 0
+    assert ((tri < 0) == (otri < 0)).all()
+    assert (pos.view(np.uint32) == opos.view(np.uint32)).all()
+    assert (info[hit] == 2).mean() > 0.9, "the tripled triangles did not force the exact re-trace"
+    n_cold = 0
+    for idx in rng.choice(sc.x_res * sc.y_res, 60, replace=False):
+        g = rm.debug_trace_pixel(int(idx), max_recs=32)
+        r = orc.trace_pixel(int(idx), max_recs=32)
+        assert len(g) >= 1 and len(r) >= 1
+        # the camera ray's closest hit: same triangle up to the copy, same position bits
+        assert (g[0].tri < 0) == (r[0].tri < 0)
+        if g[0].tri >= 0:
+            n_cold += 1
+            assert g[0].tri % 1500 == r[0].tri % 1500
+            assert tuple(np.array(list(g[0].position), np.float32).view(np.uint32)) == tuple(np.array(list(r[0].position), np.float32).view(np.uint32))
+    assert n_cold > 10
+    # nothing beside the scratch was written: the production traversal still answers the same rays the same way
+    tri2, slot2, pos2, dist2, info2 = rm.debug_trace_rays(o, d)
+    assert (pos2.view(np.uint32) == pos.view(np.uint32)).all() and (slot2 == slot).all()
+    rm.close()
+    orc.close()

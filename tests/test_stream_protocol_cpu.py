@@ -15,14 +15,16 @@ SRC = os.path.join(ROOT, "tests", "native", "ring_model.cpp")
 HDR = os.path.join(ROOT, "elevenrender_amd", "csrc", "er_ring.h")
 
 
-def _build(tmp, name, flags, guard_log2=31):
-    """guard = polls a ring wait may last before the model calls it a protocol fault.  The checked protocol never needs it, so the
-    model's is practically unbounded (2^31 polls, a millisecond of sleep every 8 192: minutes beyond the run's timeout): a wait that never ends is caught
-    by the run's own timeout instead, and a thread that is merely off its core for a long while on a busy machine -- which failed
-    correct runs twice in round 5 with a guard of 2^25 -- is not a fault.  The negative control needs a short guard: its lost entries
-    are waited for until it expires."""
+def _build(tmp, name, flags, guard_ms=120000):
+    """guard = how long a ring wait may last before the model calls it a protocol fault.  Round 6: WALL-CLOCK time (steady_clock), not a
+    poll count -- a poll count measures the machine's load (round 5 saw two correct runs end in "put guard expired" with a guard of 2^25
+    polls beside a compile job, and answered by making the guard practically unbounded, which hid a real stall just as well).  Now the
+    guard is finite again (120 s; the checked protocol never needs it) and the first expiry DUMPS the model's state once -- every ring's
+    TAIL / COUNT / HEAD and, per thread, its role and the ring position it waits for with the cell's word -- so that a thread that was
+    off its core and a wait cycle can be told apart from the run's own output.  The negative controls need a short guard: their lost
+    entries are waited for until it expires."""
     exe = str(tmp / name)
-    subprocess.run(["g++", "-std=c++17", "-pthread", "-DER_RING_HOST_MODEL", f"-DER_RING_GUARD=(1u<<{guard_log2})"] + flags + [SRC, "-o", exe], check=True)
+    subprocess.run(["g++", "-std=c++17", "-pthread", "-DER_RING_HOST_MODEL", f"-DER_RING_GUARD_MS={guard_ms}"] + flags + [SRC, "-o", exe], check=True)
     return exe
 
 
@@ -33,7 +35,7 @@ def model(tmp_path_factory):
 
 @pytest.fixture(scope="module")
 def model_short_guard(tmp_path_factory):
-    return _build(tmp_path_factory.mktemp("ring_neg"), "ring_model_neg", ["-O2"], guard_log2=19)
+    return _build(tmp_path_factory.mktemp("ring_neg"), "ring_model_neg", ["-O2"], guard_ms=500)
 
 
 @pytest.fixture(scope="module")
@@ -43,9 +45,8 @@ def model_tsan(tmp_path_factory):
 
 def _run(exe, *args, timeout=300):
     # (ER_MODEL_DEBUG: the model prints its rings' counters once a second -- a run lasts a second or two, so this is a line or two, and
-    # if a run ever stalls the assertion's message shows where.  Round 5 saw this file fail twice on a heavily loaded box -- "put guard
-    # expired" in the 16-slot / 16-pixel case, once beside a parallel compile job, once in a suite run that took five times its usual
-    # time -- and never in ~150 repetitions of the same case alone or beside 12 busy loops: NOTEBOOK.md, round 5.)
+    # if a run ever stalls the assertion's message shows where; an expired guard prints the state dump.  Round 5 saw this file fail twice
+    # on a heavily loaded box -- "put guard expired" in the 16-slot / 16-pixel case -- with one line of text and no state: NOTEBOOK.md.)
     env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1 exitcode=66", ER_MODEL_DEBUG="1")
     env.pop("LD_PRELOAD", None)      # (tools/sanitize_cpu.sh preloads the ASan runtime into python: not into a TSan binary)
     return subprocess.run([exe] + [str(a) for a in args], capture_output=True, text=True, timeout=timeout, env=env)
@@ -97,6 +98,31 @@ def test_round_2_producers_under_threads_are_usually_caught_too(model_short_guar
         assert "pixels short" in r.stdout
         caught += r.returncode != 0
     print("unchecked producers under threads: runs caught by the model:", caught, "of 3")
+
+
+def test_a_real_wait_cycle_is_refused_at_start_up_and_explains_itself_when_forced(model_short_guard):
+    """VERDICT r5 item 4.  The one capacity precondition the protocol has -- a wave's reservation must fit the ray ring, else its later
+    puts wait for readers of its OWN unpublished entries -- is checked when the model starts (the kernel: static_assert in
+    er_stream.hip).  Forced on purpose (variant 3) it is a genuine cycle: the guard expires and the dump shows its signature --
+    entries reserved and not granted with COUNT 0, the producer waiting for the reader of a cell its own entry fills, every consumer
+    idle -- which is NOT what a descheduled reader looks like (there the waited cell's reader is a granted position: HEAD has passed it)."""
+    r = _run(model_short_guard, 4, 4, 50, 0, 2, 2, 1, timeout=120)
+    assert r.returncode == 2 and "refused" in r.stderr, (r.stdout, r.stderr[-2000:])
+    r = _run(model_short_guard, 4, 4, 50, 3, 2, 2, 1, timeout=120)
+    assert r.returncode == 1, (r.stdout, r.stderr[-2000:])
+    assert "==== ring model state dump (put guard expired) ====" in r.stderr
+    assert r.stderr.count("==== ring model state dump") == 1                      # once, by the first thread whose guard expires
+    assert "ray ring    cap    2  TAIL 4  COUNT 0  HEAD 0  (reserved and not yet granted: 4)" in r.stderr
+    assert "main (camera rays) 0: WAITING" in r.stderr and "ray ring position 2 (cell 0, needs lap 1); cell word last seen: lap 0 FULL" in r.stderr
+    assert "tracer 0: not waiting on a ring cell" in r.stderr and "shader 1: not waiting on a ring cell" in r.stderr
+
+
+def test_the_kernel_asserts_its_ring_capacities():
+    """The device's producers never wait at all: its ray ring holds every ray its slots can have in flight (three per slot with the
+    light extension), its shade and finish rings every slot -- asserted where the capacities are defined."""
+    src = open(os.path.join(ROOT, "elevenrender_amd", "csrc", "er_stream.hip")).read()
+    assert "(1u << ST_RQ_LOG2) >= 3u * ER_STREAM_SLOTS" in src
+    assert "(1u << ST_SQ_LOG2) >= ER_STREAM_SLOTS" in src
 
 
 def test_kernel_and_model_share_the_ring_functions():
