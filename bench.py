@@ -604,10 +604,16 @@ def main():
                     for _ in range(3):
                         pm.render(args.steps, blocking=False)
                         ms.append(pm.wait())
+                    si = pm.stream_info()
                     pm.close()
                     share_ms = sorted(ms)[1] / args.steps
                     proj[str(n)] = {"share_ms_per_step": round(share_ms, 4), "speedup_vs_1": round((kernel_ms / args.steps) / share_ms, 3),
-                                    "value": round(value * (kernel_ms / args.steps) / share_ms, 1)}
+                                    "value": round(value * (kernel_ms / args.steps) / share_ms, 1),
+                                    # what the share ran as: owned pixels per CU, waves per workgroup and how many of them trace, the share of their
+                                    # lanes that held a ray in the last launch (the whole frame: roofline.trace_lanes.busy of the instrumented replay),
+                                    # the deal; `latency_tracer`: no second tracer role exists (priced and not built)
+                                    "pixels_per_cu": si["pixels_per_cu"], "waves": si["waves"], "tracers": si["tracers"], "lanes_busy": round(si["lanes_busy"], 4),
+                                    "large_regions": bool(si["large_regions"]), "latency_tracer": False}
                 except abi.ErError as e:
                     proj[str(n)] = {"error": str(e)}
             result["projected"] = {"what": "one GPU's share (rank 0 of N) of this frame rendered alone on this GPU, median of 3 launches of `steps` steps; "

@@ -96,6 +96,11 @@ class ErAccelInfo(C.Structure):
                 ("upload_ms", C.c_float), ("lift_bound", C.c_float), ("builder", C.c_uint32)]
 
 
+class ErStreamInfo(C.Structure):   # include/eleven_hip_debug.h
+    _fields_ = [("waves", C.c_uint32), ("tracers", C.c_uint32), ("large_regions", C.c_uint32), ("deal_pending", C.c_uint32), ("launches", C.c_uint32),
+                ("pixels_per_cu", C.c_uint32), ("lanes_busy", C.c_double), ("launch_ms", C.c_double), ("cost_spread", C.c_double)]
+
+
 class ErTraceRec(C.Structure):   # include/eleven_hip_debug.h; same layout as the oracle's OracleTraceRec
     _fields_ = [("bounce", C.c_int32), ("tri", C.c_int32), ("shadow_tri", C.c_int32), ("opaque", C.c_int32),
                 ("position", C.c_float * 3), ("wi", C.c_float * 3), ("light", C.c_float * 3), ("reduction", C.c_float * 3),
@@ -137,6 +142,9 @@ SYMBOLS = {
     "er_gather_pass": (C.c_int, [_P, C.c_int, _P, C.c_uint32]),
     "er_debug_comm_create_local": (C.c_int, [C.c_uint32, C.POINTER(_P)]),
     "er_comm_create_local": (C.c_int, [C.c_uint32, C.POINTER(_P)]),
+    "er_debug_stream_info": (C.c_int, [_P, C.POINTER(ErStreamInfo)]),
+    "er_debug_gather_buffers": (C.c_int, [_P, C.c_uint32, C.POINTER(_P), C.POINTER(C.c_uint64), C.POINTER(_P), C.POINTER(C.c_uint64)]),
+    "er_debug_comm_loopback": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_double)]),
     "er_measure_hbm_peak": (C.c_int, [C.c_int, C.c_uint64, C.c_uint32, _FP, _FP]),
     "er_debug_eval": (C.c_int, [_P, C.c_int, _FP, C.c_uint32, C.c_uint32, _FP, C.c_uint32]),
     "er_debug_trace_rays": (C.c_int, [_P, _FP, _FP, C.c_uint32, _IP, _FP, _IP, _IP, _FP, _FP, _IP]),

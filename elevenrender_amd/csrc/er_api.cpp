@@ -663,6 +663,8 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     return ER_OK;
 }
 
+static void er_stream_adapt(ErScene* s);
+
 static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     if (!s) return fail(ER_ERR_INVALID_ARG, "er_render_samples: NULL scene");
     std::lock_guard<std::mutex> lk(s->mtx);
@@ -686,11 +688,34 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
         HIP_TRY(hipEventRecord(s->prof_events[s->prof_used++], s->stream));
     }
     if (s->params.flags & ER_FLAG_STREAM) {
-        HIP_TRY(hipMemsetAsync(s->stream_ctl + 2, 0, 22 * sizeof(uint32_t), s->stream));      // the call's lane-occupancy counts, its end per XCD ...
-        HIP_TRY(hipMemsetAsync(s->stream_ctl + 6, 0xFF, 2 * sizeof(uint32_t), s->stream));    // ... and its start (a minimum)
-        if (n > 0) s->stream_launches++;
-        er_launch_stream(s->dev, s->d_dev.p, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_deal.p + s->stream_deal_off, s->stream_deal_n, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, n, count,
-                         s->stream_blocks, s->stream_tracers, s->stream_waves, s->stream);
+        auto launch = [&](uint32_t k) -> int {
+            HIP_TRY(hipMemsetAsync(s->stream_ctl + 2, 0, 22 * sizeof(uint32_t), s->stream));      // the call's lane-occupancy counts, its end per XCD ...
+            HIP_TRY(hipMemsetAsync(s->stream_ctl + 6, 0xFF, 2 * sizeof(uint32_t), s->stream));    // ... and its start (a minimum)
+            if (k > 0) s->stream_launches++;
+            er_launch_stream(s->dev, s->d_dev.p, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_deal.p + s->stream_deal_off, s->stream_deal_n, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, k, count,
+                             s->stream_blocks, s->stream_tracers, s->stream_waves, s->stream);
+            return ER_OK;
+        };
+        // Round 6: a render that is ONE call must get the deal its frame deserves too.  While the deal is undecided, the first call's
+        // first sample is a launch of its own: the kernel counts that pass's path lengths per tile (a count of work, the same on every
+        // run), the library decides -- and stops the counting -- and the other n - 1 samples run on the deal decided.  Until round 6 the
+        // decision came after the first CALL, so a host that issued one er_render_samples(256) never left the default deal (C2 -1.5 ... -4 %,
+        // C4 -3 ... -5.7 %) and `bench.py --warmup 0` measured another kernel configuration than `--warmup 5`.  Cost: one more launch per
+        // render (~0.8 ms) and a host wait of one sample pass inside this call, once; the image does not depend on the deal.
+        static const bool split_first = [] { const char* e = getenv("ER_STREAM_SPLIT_FIRST"); return !(e && atoi(e) == 0); }();      // (A/B knob)
+        if (s->stream_deal_pending && n >= 2u && split_first) {
+            int rc = launch(1u);
+            if (rc != ER_OK) return rc;
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            if ((rc = er_scene_stream_status(s, "er_render_samples")) != ER_OK) return rc;
+            s->stream_probe_launch = true;      // (a one-pass launch is no reading of the tracer lanes' occupancy: only the deal is decided on it)
+            er_stream_adapt(s);
+            s->stream_probe_launch = false;
+            n -= 1u;
+        }
+        int rc = launch(n);
+        if (rc != ER_OK) return rc;
     } else if (s->params.flags & ER_FLAG_MEGAKERNEL) {
         er_launch_render(s->dev, n, count, s->stream);
     }
@@ -816,7 +841,7 @@ static void er_stream_adapt(ErScene* s) {
     }
     if (verbose && (s->params.flags & ER_FLAG_STREAM) && s->stream_xcd_spread >= 0.0)
         fprintf(stderr, "[er_stream] XCDs finished %.3f of the launch apart (a measured time: printed, nothing is decided on it)\n", s->stream_xcd_spread);
-    if (!s->stream_adapt || !(s->params.flags & ER_FLAG_STREAM) || s->stream_busy <= 0.0) return;
+    if (!s->stream_adapt || !(s->params.flags & ER_FLAG_STREAM) || s->stream_busy <= 0.0 || s->stream_probe_launch) return;
     const uint32_t lo = s->stream_waves == 12 ? 7u : 10u;
     const uint32_t before = s->stream_tracers;
     // (ER_STREAM_FORCE_BUSY: test knob -- the reading the mechanism is driven with instead of the measured one, whatever the launch's length;

@@ -267,7 +267,54 @@ static int er_gather_pass_impl(ErScene* s, int pass, ErComm* c, uint32_t root) {
     return er_scene_stream_status(s, "er_gather_pass");
 }
 
+static int er_debug_gather_buffers_impl(ErScene* s, uint32_t peer, void** in_ptr, uint64_t* in_bytes, void** mine_ptr, uint64_t* mine_bytes) {
+    if (!s) return fail(ER_ERR_INVALID_ARG, "er_debug_gather_buffers: NULL scene");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    auto it = s->d_gather_in.find(peer);
+    if (in_ptr) *in_ptr = it == s->d_gather_in.end() ? nullptr : (void*)it->second.p;
+    if (in_bytes) *in_bytes = it == s->d_gather_in.end() ? 0 : (uint64_t)it->second.n * sizeof(float4);
+    if (mine_ptr) *mine_ptr = (void*)s->d_gather_mine.p;
+    if (mine_bytes) *mine_bytes = (uint64_t)s->d_gather_mine.n * sizeof(float4);
+    return ER_OK;
+}
+
+static int er_debug_comm_loopback_impl(ErComm* c, uint64_t bytes, double* ms) {
+    if (!c || bytes == 0 || bytes % 4 != 0) return fail(ER_ERR_INVALID_ARG, "er_debug_comm_loopback: bad argument");
+    if (c->device >= 0) HIP_TRY(hipSetDevice(c->device));
+    ScopedDevBuf<uint32_t> src, dst;
+    const size_t n = (size_t)(bytes / 4);
+    std::vector<uint32_t> pat(n), back(n, 0u);
+    for (size_t i = 0; i < n; i++) pat[i] = (uint32_t)(i * 2654435761u) ^ 0x5bd1e995u;
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } guard{st};
+    int rc;
+    if ((rc = upload(src, pat.data(), n, st)) != ER_OK) return rc;
+    if ((rc = upload(dst, (const uint32_t*)nullptr, n, st)) != ER_OK) return rc;
+    HIP_TRY(hipMemsetAsync(dst.p, 0, bytes, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((rc = c->t.group_start(c->self)) != ER_OK) return rc;
+    rc = c->t.send(c->self, src.p, (size_t)bytes, c->rank, st);
+    int rc1 = rc == ER_OK ? c->t.recv(c->self, dst.p, (size_t)bytes, c->rank, st) : ER_OK;
+    int rc2 = c->t.group_end(c->self);
+    if (rc != ER_OK) return rc;
+    if (rc1 != ER_OK) return rc1;
+    if (rc2 != ER_OK) return rc2;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    HIP_TRY(hipMemcpy(back.data(), dst.p, bytes, hipMemcpyDeviceToHost));
+    if (back != pat) return fail(ER_ERR_STATE, std::string("er_debug_comm_loopback: the bytes received over the ") + c->t.name + " transport differ from the bytes sent");
+    return ER_OK;
+}
+
 extern "C" {
+int er_debug_gather_buffers(ErScene* s, uint32_t peer, void** in_ptr, uint64_t* in_bytes, void** mine_ptr, uint64_t* mine_bytes) {
+    return guarded("er_debug_gather_buffers", [&]() -> int { return er_debug_gather_buffers_impl(s, peer, in_ptr, in_bytes, mine_ptr, mine_bytes); });
+}
+int er_debug_comm_loopback(ErComm* c, uint64_t bytes, double* ms) {
+    return guarded("er_debug_comm_loopback", [&]() -> int { return er_debug_comm_loopback_impl(c, bytes, ms); });
+}
 int er_comm_unique_id(uint8_t* id) { return guarded("er_comm_unique_id", [&]() -> int { return er_comm_unique_id_impl(id); }); }
 int er_comm_create(const uint8_t* id, uint32_t rank, uint32_t world, int device, ErComm** out) {
     return guarded("er_comm_create", [&]() -> int { return er_comm_create_impl(id, rank, world, device, out); });

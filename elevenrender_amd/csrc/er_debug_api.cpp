@@ -263,7 +263,23 @@ static int er_measure_hbm_peak_impl(int device, uint64_t bytes, uint32_t iters, 
 extern "C" void er_debug_set_host_alloc_limit(uint64_t bytes) { g_host_alloc_limit.store(bytes); }
 
 
+static int er_debug_stream_info_impl(ErScene* s, ErStreamInfo* out) {
+    if (!s || !out) return fail(ER_ERR_INVALID_ARG, "er_debug_stream_info: NULL argument");
+    std::lock_guard<std::mutex> lk(s->mtx);
+    memset(out, 0, sizeof(*out));
+    out->cost_spread = -1.0;
+    if (!s->begun || !(s->params.flags & ER_FLAG_STREAM)) return ER_OK;
+    out->waves = s->stream_waves; out->tracers = s->stream_tracers;
+    out->large_regions = (s->stream_deal_alt_n != 0u && s->stream_deal_off == s->stream_deal_alt_off && s->stream_deal_n == s->stream_deal_alt_n) ? 1u : 0u;
+    out->deal_pending = s->stream_deal_pending ? 1u : 0u;
+    out->launches = (uint32_t)s->stream_launches;
+    out->pixels_per_cu = (uint32_t)((size_t)s->dev.owned_tile_count * 64 / std::max<uint32_t>(1u, s->stream_blocks));
+    out->lanes_busy = s->stream_busy; out->launch_ms = s->stream_launch_ms; out->cost_spread = s->stream_cost_spread;
+    return ER_OK;
+}
+
 extern "C" {
+int er_debug_stream_info(ErScene* s, ErStreamInfo* out) { return guarded("er_debug_stream_info", [&]() -> int { return er_debug_stream_info_impl(s, out); }); }
 int er_debug_closest_hit(ErScene* s, const float* origins, const float* dirs, uint32_t n, int32_t* tri_ids, float* positions, float* distances) { return guarded("er_debug_closest_hit", [&]() -> int { return er_debug_closest_hit_impl(s, origins, dirs, n, tri_ids, positions, distances); }); }
 int er_debug_cdf_search(const float* cdf, int length, const float* values, int32_t* out, int count) { return guarded("er_debug_cdf_search", [&]() -> int { return er_debug_cdf_search_impl(cdf, length, values, out, count); }); }
 int er_debug_stream_deal(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, int xcd_aware, uint32_t edge, uint32_t* out, uint32_t out_cap, uint32_t* most) {

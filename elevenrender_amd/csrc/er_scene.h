@@ -194,6 +194,7 @@ struct ErScene {
     uint32_t stream_low_streak = 0, stream_up_budget = 1, stream_tracers_start = 0, stream_readings = 0;   //   er_stream_adapt: consecutive low readings; steps back up left; the split the render began with
     uint32_t stream_deal_off = 0, stream_deal_n = 0;    //   the deal in use inside d_deal (entries): the one of large super-tiles first, the default edge's after it
     uint32_t stream_deal_alt_off = 0, stream_deal_alt_n = 0;   //   the deal of large screen regions beside it (0 entries: none)
+    bool stream_probe_launch = false;                   //   the launch just completed was the first sample of a render's first call, run alone to decide the deal (er_render_samples)
     bool stream_deal_pending = false;                   //   the first completed call decides between the two (er_stream_adapt), from ...
     DevBuf<uint32_t> d_tile_cost;                       //   ... DevScene::tile_cost: per tile of the frame, the summed path lengths of its finished samples
     std::vector<uint32_t> stream_deal_large;            //   host copy of the large deal until then (which XCD gets which tile under it)

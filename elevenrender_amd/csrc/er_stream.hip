@@ -78,6 +78,22 @@ __device__ __forceinline__ void sp_add(unsigned long long* c, uint32_t d) { atom
 #define ER_SP(x)
 #endif
 
+// Diagnostic build (-DER_TRACER_PROBE, tools/tracer_probe.py): where does an iteration of a tracer wave spend its time?  Every tracer wave
+// stamps s_memtime at the boundaries of its loop's parts and adds the cycles since the previous stamp to one of seven wave-uniform sums
+// (ring visit: publish + refill / choose / loads issued + wait for the triangle pieces / triangle block / wait for the node pieces + the
+// LDS copy / node block / idle polls); the sums, the iterations, the lanes that held a ray and the numbers of publishes and refills come
+// back in the event counters (meaningless otherwise in this build).
+#ifdef ER_TRACER_PROBE
+#define ER_TRP(i)                                                           \
+    {                                                                       \
+        const unsigned long long trp_now = __builtin_amdgcn_s_memtime();    \
+        trp[i] += (uint32_t)(trp_now - trp_last);                           \
+        trp_last = trp_now;                                                 \
+    }
+#else
+#define ER_TRP(i) ((void)0)
+#endif
+
 namespace {
 
 #define ST_SLOT_BITS 11          // ring payloads: local slot (11 bits) | kind or flag (2 bits) = ER_RING_PAYLOAD_BITS
@@ -398,6 +414,10 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
             uint32_t idle = 0, progress = 0;
             uint32_t a_iter = 0, a_busy = 0;      // iterations of this wave's loop and the lanes that held a ray in them (-> status[1..4])
             ER_SP(uint32_t spA = 0; uint32_t spB = 0; uint32_t spC = 0; uint32_t sAB = 0; uint32_t sBC = 0; uint32_t sCD = 0; uint32_t sN = 0;)      // (per lane, flushed once at the end)
+#ifdef ER_TRACER_PROBE
+            uint32_t trp[7] = {0, 0, 0, 0, 0, 0, 0}, trp_pub = 0, trp_take = 0;
+            unsigned long long trp_last = __builtin_amdgcn_s_memtime();
+#endif
             while (true) {
                 ER_MARK("tracer_loop_top");
                 // Every refill_min idle lanes the wave does its ring work in one go: FIRST the finished rays of the idle lanes are
@@ -410,6 +430,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 const bool visit = 64u - (unsigned)__popcll(bm0) >= refill_min || bm0 == 0;
                 if (visit && __ballot(done)) {
                     ER_MARK("tracer_publish");
+#ifdef ER_TRACER_PROBE
+                    trp_pub++;
+#endif
                     const uint32_t ls = lsk & ST_SLOT_MASK, kind = lsk >> ST_SLOT_BITS;
                     if (done) st_write_result(W, g0 + ls + (kind == 2u ? W.slots : 0u), T.shadow, done_occl, T.overflow, T.s0, T.s1);
                     ER_SP(if (done && kind == 0u) { const uint32_t spD = sp_now(); sAB += spB - spA; sBC += spC - spB; sCD += spD - spC; sN++; W.stamp(g0 + ls) = spD; })
@@ -436,6 +459,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                     uint32_t hb = 0;
                     const uint32_t granted = st_take(s_rq_ctl, 64u - (uint32_t)__popcll(bm0), hb, rq_peek);
                     const bool take = !busy && (uint32_t)__popcll(~bm0 & below) < granted;
+#ifdef ER_TRACER_PROBE
+                    if (granted > 0) trp_take++;
+#endif
                     if (granted > 0) {
                         uint32_t e = 0;
                         bool got = false;
@@ -464,6 +490,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 if (bm == 0) {
                     if (v_ctl[C_DONE]) break;
                     __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
+                    ER_TRP(6);
                     const uint32_t pr = er_ring_load(&s_rq_ctl[ER_RING_TAIL]) + er_ring_load(&s_sq_ctl[ER_RING_TAIL]) + er_ring_load(&s_fq_ctl[ER_RING_TAIL]);
                     if (pr != progress) { progress = pr; idle = 0; }
                     if (++idle > ST_WATCHDOG) {
@@ -475,6 +502,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 idle = 0;
                 a_iter++;                                   // (wave-uniform: two scalar operations per iteration)
                 a_busy += (uint32_t)__popcll(bm);
+                ER_TRP(0);
 #ifdef ER_TIME_PROBE
                 const unsigned long long tr0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -494,6 +522,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 }
                 TravData D;
                 ER_MARK("tracer_fetch");
+                ER_TRP(1);
                 const bool top = st.node && st.noff < (uint32_t)(TOP_NODES * ER_NODE8_PIECES);
 #if ER_STREAM_SPLIT_WAIT
                 bool occl = false;
@@ -503,14 +532,17 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                     TravRaw R;
                     trav_fetch_issue(S, sg, R);
                     trav_wait_tri(R, D);
+                    ER_TRP(2);
                     ER_MARK("tracer_apply");
                     // the triangle block while the node pieces are still on their way
                     const bool do_tri = busy && do_step;
                     TravStep stt = st;
                     stt.tri = st.tri && do_tri;
                     occl = trav_apply_tri<COUNT>(T, S, stt, D, c_tris);
+                    ER_TRP(3);
                     trav_wait_node(R, D);
                     if (top) trav_node_from_lds(D, s_top, st.noff);
+                    ER_TRP(4);
                     TravStep sn = st;
                     sn.node = st.node && do_tri && !occl;
                     trav_apply_node<COUNT>(T, S, sn, D, c_nodes);
@@ -537,8 +569,21 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 if (lane == 0) atomicAdd(&s_tp[12], (unsigned)((__builtin_amdgcn_s_memtime() - tr0) >> 4));
 #endif
                 ER_MARK("tracer_iter_end");
+                ER_TRP(5);
             }
             ER_MARK("tracer_loop_end");
+#ifdef ER_TRACER_PROBE
+            const unsigned trp_rays = st_wave_sum(c_rays);
+            if (lane == 0) {
+                unsigned long long* c = (unsigned long long*)&S.counters->node_visits;      // node_visits ... trace_tri_lanes: nine 64-bit sums
+                for (int i = 0; i < 7; i++) atomicAdd(&c[i], (unsigned long long)trp[i]);
+                atomicAdd(&c[7], (unsigned long long)trp_pub);
+                atomicAdd(&c[8], (unsigned long long)trp_take);
+                atomicAdd(&S.counters->paths, (unsigned long long)a_iter);
+                atomicAdd(&S.counters->bounce_samples, (unsigned long long)a_busy);
+                atomicAdd(&S.counters->rays, (unsigned long long)trp_rays);
+            }
+#endif
             ER_SP({ unsigned long long* spc = (unsigned long long*)&S.counters->node_visits; sp_add(spc + 0, sAB); sp_add(spc + 1, sBC); sp_add(spc + 2, sCD); sp_add(spc + 5, sN); })
             // how full the tracer lanes were: the host reads it after the call and moves one wave between the two roles for the next
             // call when the tracers starve or the shaders idle (er_api.cpp, er_stream_adapt)
@@ -866,7 +911,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
         ER_SP({ unsigned long long* spc = (unsigned long long*)&S.counters->node_visits; sp_add(spc + 3, sDE); sp_add(spc + 4, sEF); sp_add(spc + 6, sGE); sp_add(spc + 7, sNG); sp_add(spc + 8, sSS); atomicAdd(&S.counters->paths, (unsigned long long)sNS); })
     }
     ER_MARK("epilogue");
-#ifdef ER_STAGE_PROBE
+#if defined(ER_STAGE_PROBE) || defined(ER_TRACER_PROBE)
     return;
 #endif
 #ifdef ER_TIME_PROBE

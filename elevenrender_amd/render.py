@@ -136,6 +136,12 @@ class RenderingManager:
         abi.check(self.lib.er_get_profile(self.handle, C.byref(pr)))
         return {n: getattr(pr, n) for n, _ in abi.ErProfile._fields_}
 
+    def stream_info(self):
+        """include/eleven_hip_debug.h: the streaming schedule's configuration and readings of the last completed call."""
+        si = abi.ErStreamInfo()
+        abi.check(self.lib.er_debug_stream_info(self.handle, C.byref(si)))
+        return {n: getattr(si, n) for n, _ in abi.ErStreamInfo._fields_}
+
     def accel_info(self):
         a = abi.ErAccelInfo()
         abi.check(self.lib.er_accel_info(self.handle, C.byref(a)))

@@ -101,6 +101,31 @@ int er_debug_eval(struct ErScene* scene, int kind, const float* in, uint32_t n, 
 struct ErComm;
 int er_debug_comm_create_local(uint32_t world, struct ErComm** out);
 
+/* What the streaming schedule ran the last completed call with, and what it read from it (er_api.cpp er_stream_adapt): for bench.py's
+ * `projected` block and the tests.  Valid after er_wait / a read-back; all zero for the other schedules. */
+typedef struct ErStreamInfo {
+    uint32_t waves, tracers;       /* waves per workgroup (16 or 12) and how many of them trace */
+    uint32_t large_regions;        /* 1: the deal of 16 x 16-tile screen regions per XCD is in use; 0: the default 8 x 8 one */
+    uint32_t deal_pending;         /* 1: the deal is still to be decided (no call has completed) */
+    uint32_t launches;             /* kernel launches of this render so far */
+    uint32_t pixels_per_cu;        /* owned pixels per workgroup (tiles x 64 / workgroups) */
+    double lanes_busy;             /* share of the tracer waves' lanes that held a ray, last completed launch */
+    double launch_ms;              /* device time of that launch */
+    double cost_spread;            /* (max - min) / mean of the XCDs' counted work under the large deal; < 0: not decided */
+} ErStreamInfo;
+int er_debug_stream_info(struct ErScene* s, ErStreamInfo* out);
+
+/* The buffers er_gather_pass keeps on a scene (round 5: allocated by the first gather, reused by every later one): the receive
+ * buffer for `peer`'s pixels on the root (*in_ptr, *in_bytes; NULL / 0 before the first gather or for peer == own rank) and the
+ * packed send buffer of a non-root rank (*mine_ptr, *mine_bytes).  Device pointers, for identity comparison only. */
+int er_debug_gather_buffers(struct ErScene* s, uint32_t peer, void** in_ptr, uint64_t* in_bytes, void** mine_ptr, uint64_t* mine_bytes);
+
+/* `bytes` of a known pattern from this rank to ITSELF through the communicator's transport table -- group start, send(self),
+ * recv(self), group end on a stream of the library's own -- and compared after the stream has drained: the one exchange RCCL
+ * allows on a one-GPU box (it refuses two ranks on one device), so that ncclSend / ncclRecv of the dlopen'd library have carried
+ * bytes from the C++ side before the first multi-GPU run.  *ms = wall time of the exchange.  ER_ERR_STATE if the bytes differ. */
+int er_debug_comm_loopback(struct ErComm* c, uint64_t bytes, double* ms);
+
 /* The streaming schedule's deal of a rank's owned 8 x 8 tiles (`owned`: tile indices ty * tiles_x + tx) to `blocks` workgroups, as
  * er_render_begin makes it (host code, no device needed): out[b + k * blocks] = the k-th tile of workgroup b or 0xFFFFFFFF, for
  * k < *most; workgroups b and b + 8 share an XCD.  edge = side of a super-tile in tiles, 0 = the library's default.  out_cap >= blocks * *most

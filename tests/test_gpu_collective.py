@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from elevenrender_amd import abi, render, scenes
+from elevenrender_amd import dist as erdist
 from test_gpu_parity import gpu_render
 
 pytestmark = pytest.mark.gpu
@@ -175,13 +176,58 @@ def test_c3_eight_ranks_of_the_c2_frame_gathered_equal_the_single_gpu_frame():
         paths += rm.counters()["paths"]
         assert rm.profile()["schedule"] == abi.FLAG_STREAM
     assert paths == 1920 * 1080 * spp
+    # (round 6) the buffers of the gather are the exact ones of an 8-way split of a 1080p frame -- 4 050 or 4 051
+    # tiles x 64 pixels x 16 bytes per rank, 4.1 MB -- allocated by the FIRST plane's gather and reused by the other four: the same
+    # device pointers after every plane (a five-plane read-back from seven peers was 35 hipMalloc / hipFree pairs until round 5)
+    def buffers(r, peer):
+        ip, ib, mp, mb_ = C.c_void_p(), C.c_uint64(), C.c_void_p(), C.c_uint64()
+        abi.check(lib.er_debug_gather_buffers(rms[r].handle, peer, C.byref(ip), C.byref(ib), C.byref(mp), C.byref(mb_)))
+        return ip.value, ib.value, mp.value, mb_.value
+    tiles_of = [len(erdist.owned_tiles(r, world, 1920, 1080)) for r in range(world)]
+    assert sum(tiles_of) == 240 * 135 and max(tiles_of) - min(tiles_of) <= 1
+    first = None
     for p in range(abi.PASS_COUNT):
         for r in [x for x in range(world) if x != root] + [root]:
             abi.check(lib.er_gather_pass(rms[r].handle, p, comms[r], root))
+        now = {("in", peer): buffers(root, peer)[:2] for peer in range(world) if peer != root}
+        now.update({("mine", r): buffers(r, root)[2:] for r in range(world) if r != root})
+        if first is None:
+            first = now
+            for peer in range(world):
+                if peer != root:
+                    assert now[("in", peer)] == (now[("in", peer)][0], tiles_of[peer] * 64 * 16) and now[("in", peer)][0]
+                    assert now[("mine", peer)] == (now[("mine", peer)][0], tiles_of[peer] * 64 * 16) and now[("mine", peer)][0]
+            assert buffers(root, root)[:2] == (None, 0)          # the root receives nothing from itself
+        assert now == first, p                                   # pointer-stable across the five planes
     for name in abi.PASS_NAMES:
         got = rms[root].get_pass(name)
         assert (got.view(np.uint32) == full[name].view(np.uint32)).all(), name
     for rm in rms:
         rm.close()
+    for c in comms:
+        lib.er_comm_destroy(c)
+
+
+def test_rccl_carries_bytes_from_the_c_side_a_self_exchange_through_the_transport_table():
+    """"RCCL from C++ has never carried a byte".  RCCL refuses two ranks on one device, so on a one-GPU box the only
+    exchange it allows is a rank's send to ITSELF: group start, ncclSend(self), ncclRecv(self), group end -- through the same
+    transport table, dlopen'd symbols, datatype and stream arguments er_gather_pass uses -- with one peer buffer of an 8-way 1080p
+    split (4 051 tiles x 64 pixels x 16 bytes) and a single float4; the bytes received must be the bytes sent.  The in-process
+    transport goes through the same hook."""
+    lib = abi.load()
+    ident = (C.c_uint8 * 128)()
+    abi.check(lib.er_comm_unique_id(ident))
+    comm = C.c_void_p()
+    abi.check(lib.er_comm_create(ident, 0, 1, 0, C.byref(comm)))
+    for nbytes in (16, 4051 * 64 * 16):
+        ms = C.c_double()
+        abi.check(lib.er_debug_comm_loopback(comm, nbytes, C.byref(ms)))
+        print(f"RCCL self exchange of {nbytes} bytes: {ms.value:.3f} ms")
+    lib.er_comm_destroy(comm)
+    comms = (C.c_void_p * 2)()
+    abi.check(lib.er_debug_comm_create_local(2, comms))
+    ms = C.c_double()
+    abi.check(lib.er_debug_comm_loopback(comms[1], 4051 * 64 * 16, C.byref(ms)))
+    assert lib.er_debug_comm_loopback(comms[1], 6, C.byref(ms)) == abi.ER_ERR_INVALID_ARG
     for c in comms:
         lib.er_comm_destroy(c)

@@ -595,6 +595,19 @@ def test_deal_is_decided_by_counted_work_and_the_image_does_not_change(monkeypat
         assert ("-> large regions" in lines[0]) == (limit is not None), lines
         assert ("the default deal stays" in lines[0]) == (limit is None), lines
     assert figures[0] == figures[1] == figures[2] and figures[0] > 0.1, figures      # counted, not timed: the same figure every time
+    # Round 6: a render that is ONE call decides too -- the call's first sample is a launch of its own, the decision
+    # follows it (the same figure: the work counted is that first pass's in both cases) and the other samples run on the deal decided.
+    for limit in (None, "1e9"):
+        if limit is None:
+            monkeypatch.delenv("ER_STREAM_COST_SPREAD_MAX", raising=False)
+        else:
+            monkeypatch.setenv("ER_STREAM_COST_SPREAD_MAX", limit)
+        capfd.readouterr()
+        outs.append(gpu_render(sc, 12, max_bounces=8, flags=abi.FLAG_STREAM, chunks=[12]))
+        err = capfd.readouterr().err.splitlines()
+        lines = [l for l in err if l.startswith("[er_stream] counted work")]
+        assert len(lines) == 1 and float(lines[0].split(":")[1].split("of the mean")[0]) == figures[0], lines
+        assert ("-> large regions" in lines[0]) == (limit is not None), lines
     for other in [fixed16] + outs:
         for p in ("beauty", "normal", "tangent", "bitangent"):
             assert (fixed8[p].view(np.uint32) == other[p].view(np.uint32)).all(), p
