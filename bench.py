@@ -186,8 +186,8 @@ def make_scene(args, scenes, abi):
         what = f"C2: {args.tris}-triangle random soup + 2048x1024 sky HDRI, {w}x{h}"
     elif args.config == "C4":
         w, h = args.width or 3840, args.height or 2160
-        sc = scenes.blob_instances(x_res=w, y_res=h)
-        what = f"C4: {sc.tri_count} triangles (10 000 instances of a 1 000-triangle smooth-normal blob, flattened) + sky HDRI, {w}x{h}"
+        sc = scenes.blob_instances(tris_per_blob=args.blob_tris, x_res=w, y_res=h)
+        what = f"C4: {sc.tri_count} triangles (10 000 instances of a {args.blob_tris}-triangle smooth-normal blob, flattened) + sky HDRI, {w}x{h}"
     else:
         w, h = args.width or 1920, args.height or 1080
         sc = scenes.torture(args.tris, w, h, seed=12345)
@@ -218,6 +218,8 @@ def main():
     ap.add_argument("--schedule", choices=["auto", "wavefront", "megakernel", "stream"], default="auto")
     ap.add_argument("--gpu-build", action="store_true", help="force the device BVH build (ER_FLAG_GPU_BUILD; the default for scenes of >= 20 000 triangles since round 5)")
     ap.add_argument("--host-build", action="store_true", help="force the host BVH build (ER_FLAG_HOST_BUILD)")
+    ap.add_argument("--blob-tris", type=int, default=1000, help="(C4, diagnostic) triangles per blob: the same 10 000 blobs at another tessellation -- the same frame with "
+                    "another working set (tools/c4_working_set_sweep.sh); 1000 is BASELINE config 4")
     ap.add_argument("--sim-world", type=int, default=0, help="(diagnostic) render only rank --sim-rank's tiles of this many, no collective")
     ap.add_argument("--sim-rank", type=int, default=0)
     ap.add_argument("--no-projection", action="store_true", help="skip the `projected` block (N = 1 only): rank 0's share of a 2-, 4- and 8-way tile split rendered alone on this GPU")

@@ -150,6 +150,7 @@ SYMBOLS = {
     "er_debug_trace_rays": (C.c_int, [_P, _FP, _FP, C.c_uint32, _IP, _FP, _IP, _IP, _FP, _FP, _IP]),
     "er_debug_trace_pixel": (C.c_int, [_P, C.c_uint32, C.POINTER(ErTraceRec), C.c_int, C.POINTER(C.c_int)]),
     "er_debug_set_host_alloc_limit": (None, [C.c_uint64]),
+    "er_debug_set_gpu_build_failure": (None, [C.c_int]),
     "er_debug_closest_hit": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_float),
                                        C.POINTER(C.c_float)]),
 }

@@ -201,9 +201,15 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         ErGpuSceneArrays arrays{s->vertices.data(), s->normals.data(), s->tangents.data(), s->uvs.data(), s->tangent_sign.data(), s->material_id.data()};
         ErGpuBvhDevice g;
         int brc = er_gpu_build_device(arrays, s->tri_count, s->device, &g, why);
-        if (brc < 0 && force_dev) return fail(ER_ERR_HIP, "er_render_begin: device BVH build: " + why);
-        if (brc != 0 && getenv("ER_GPU_BUILD_VERBOSE")) fprintf(stderr, "[er_gpu_build] %s: the host builds instead\n", why.c_str());
-        if (brc < 0) (void)hipGetLastError();      // (a failed default build -- device memory, say -- is not the call's failure: the host builder takes over)
+        if (brc < 0 && force_dev) return fail(brc == -2 ? ER_ERR_OOM : ER_ERR_HIP, "er_render_begin: device BVH build: " + why);
+        // What a default device build that did not deliver means: a DECLINE (> 0: too few triangles, a tree deeper than the
+        // traversal stacks) and OUT OF DEVICE MEMORY (-2: the build's transient buffers beside other scenes or ranks) are ordinary -- the
+        // host builder takes over silently (ER_GPU_BUILD_VERBOSE says so).  Anything else (-1: a HIP error, one of the builder's own
+        // guards) is a fault of the builder: the host build still takes over -- the caller gets its image -- but never silently:
+        // one line on stderr, unconditionally, with the reason.
+        if (brc < 0) (void)hipGetLastError();
+        if (brc == -1) fprintf(stderr, "[eleven_hip] er_render_begin: the device BVH build FAILED (%s); the host builder takes over (seconds instead of milliseconds at this size) -- please report\n", why.c_str());
+        else if (brc != 0 && getenv("ER_GPU_BUILD_VERBOSE")) fprintf(stderr, "[er_gpu_build] %s: the host builds instead\n", why.c_str());
         if (brc == 0) {
             // the scene owns the three buffers from here on (release_device frees them on any later error)
             s->d_nodes.release(); s->d_nodes8.release(); s->d_attr.release();

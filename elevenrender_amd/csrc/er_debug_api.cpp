@@ -279,6 +279,7 @@ static int er_debug_stream_info_impl(ErScene* s, ErStreamInfo* out) {
 }
 
 extern "C" {
+void er_debug_set_gpu_build_failure(int kind) { er_debug_gpu_build_failure.store(kind < 0 || kind > 2 ? 0 : kind); }
 int er_debug_stream_info(ErScene* s, ErStreamInfo* out) { return guarded("er_debug_stream_info", [&]() -> int { return er_debug_stream_info_impl(s, out); }); }
 int er_debug_closest_hit(ErScene* s, const float* origins, const float* dirs, uint32_t n, int32_t* tri_ids, float* positions, float* distances) { return guarded("er_debug_closest_hit", [&]() -> int { return er_debug_closest_hit_impl(s, origins, dirs, n, tri_ids, positions, distances); }); }
 int er_debug_cdf_search(const float* cdf, int length, const float* values, int32_t* out, int count) { return guarded("er_debug_cdf_search", [&]() -> int { return er_debug_cdf_search_impl(cdf, length, values, out, count); }); }

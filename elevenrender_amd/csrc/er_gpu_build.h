@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 #include "er_bvh.h"
@@ -13,7 +14,8 @@
 // Whole structure on the device: binary tree, SAH-optimal collapse into 8-wide nodes, final slot order and the
 // triangle records, in the buffers er_render_begin hands to the kernels.  Nothing but a few counters comes back.
 // Returns 0 on success; > 0 = the device builder declines (too few triangles, tree deeper than the traversal stack
-// bound) and the caller should use er_build_bvh; < 0 = HIP error.  `err` gets the reason.
+// bound) and the caller should use er_build_bvh; -2 = out of device memory, -1 = any other HIP error or a guard of the builder
+// itself (a fault: the caller says so).  `err` gets the reason.
 struct ErGpuSceneArrays {        // host arrays of the scene, per original triangle
     const float* vertices;       // [n][3][3]
     const float* normals;        // [n][3][3]
@@ -31,4 +33,7 @@ struct ErGpuBvhDevice {
     float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, lift_bound = 0;
     double build_ms = 0;
 };
+// Test hook (include/eleven_hip_debug.h er_debug_set_gpu_build_failure): 0 = none; 1 = device builds fail as a fault inside the builder
+// would; 2 = as a device out-of-memory would.  (Until round 6 an environment variable read on the production path.)
+inline std::atomic<int> er_debug_gpu_build_failure{0};
 int er_gpu_build_device(const ErGpuSceneArrays& arrays, uint32_t n, int device, ErGpuBvhDevice* out, std::string& err);

@@ -645,7 +645,7 @@ struct Dev {
 #define GB_OK(x)                                                                             \
     do {                                                                                     \
         hipError_t e_ = (x);                                                                 \
-        if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return -1; } \
+        if (e_ != hipSuccess) { err = std::string(#x) + ": " + hipGetErrorString(e_); return e_ == hipErrorOutOfMemory ? -2 : -1; } \
     } while (0)
 
 // everything the build keeps on the device between its stages
@@ -695,7 +695,10 @@ struct GpuBuild {
     int sah(std::string& err) {
         const uint32_t blocks = (n + 255) / 256;
         const uint32_t act_cap = n / (ER_BVH_LEAF_MAX + 1) + 2;                       // an active node holds more than ER_BVH_LEAF_MAX triangles
-        const uint32_t bin_cap = std::min<uint32_t>(act_cap, 1u << 20);               // bins for this many nodes at a time (1.3 GB); a fuller round runs in chunks
+        // bins for this many nodes at a time; a fuller round runs in chunks (each chunk's bin kernel scans the triangles once more: at 10 M
+        // triangles the two or three widest levels take 13 scans instead of 4, a few ms of 330).  2^18 nodes x 1 344 B = 352 MB; 2^20 (1.4 GB)
+        // until round 6, which on a GPU that holds other scenes or ranks turned into the host fallback for want of memory
+        const uint32_t bin_cap = std::min<uint32_t>(act_cap, 1u << 18);
         Dev<float> d_cen;
         Dev<uint32_t> d_idx[2], d_flag, d_scan, d_kids, d_koff;
         Dev<int> d_nof[2];
@@ -794,7 +797,10 @@ hipError_t er_probe_gpu_build(const char** which) {   // see er_kernels.h
 int er_gpu_build_device(const ErGpuSceneArrays& a, uint32_t n, int device, ErGpuBvhDevice* out, std::string& err) {
     auto t0 = std::chrono::steady_clock::now();
     if (n <= ER_BVH_LEAF_MAX) { err = "too few triangles for the device builder"; return 1; }
-    if (getenv("ER_DEBUG_GPU_BUILD_FAIL")) { err = "simulated failure (ER_DEBUG_GPU_BUILD_FAIL)"; return -1; }      // (test knob: the caller's fallback to the host build)
+    if (const int dbg = er_debug_gpu_build_failure.load()) {      // (test hook er_debug_set_gpu_build_failure: the caller's handling of a failed build)
+        err = dbg == 2 ? "simulated failure: out of device memory" : "simulated failure: a fault inside the builder";
+        return dbg == 2 ? -2 : -1;
+    }
     GpuBuild B;
     int rc = B.binary(a.vertices, a.normals, n, device, err);
     if (rc != 0) return rc;

@@ -138,6 +138,11 @@ int er_debug_stream_deal(const uint32_t* owned, uint32_t count, uint32_t tiles_x
  * std::bad_alloc would, which the entry point must turn into ER_ERR_OOM (no exception crosses the C ABI).  0 = off. */
 void er_debug_set_host_alloc_limit(uint64_t bytes);
 
+/* Test hook for er_render_begin's handling of a device BVH build that does not deliver: 0 = off; 1 = every device build fails as a
+ * fault inside the builder would (default builder: one line on stderr and the host builder takes over; ER_FLAG_GPU_BUILD: ER_ERR_HIP);
+ * 2 = as running out of device memory would (default builder: silent host fallback; ER_FLAG_GPU_BUILD: ER_ERR_OOM). */
+void er_debug_set_gpu_build_failure(int kind);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,20 +109,30 @@ def test_device_builder_on_coincident_centroids_and_tiny_scenes():
         assert (h["samples"] == d["samples"]).all()
 
 
-def test_a_failed_default_device_build_falls_back_to_the_host_build(monkeypatch):
-    """The device builder is the default from 20 000 triangles up; if it fails (simulated here: ER_DEBUG_GPU_BUILD_FAIL) the call does
-    not -- the host builder takes over and the image is the same -- unless the caller had forced the device build, in which case its
-    failure is the call's (ER_ERR_HIP with the reason)."""
+def test_a_failed_default_device_build_falls_back_to_the_host_build(capfd):
+    """The device builder is the default from 20 000 triangles up; if it does not deliver (simulated: er_debug_set_gpu_build_failure) the
+    call still does -- the host builder takes over and the image is the same -- SILENTLY when the device was out of memory, with one
+    line on stderr when the builder itself failed (a builder fault must not pass for an OOM); if the caller had forced the
+    device build its failure is the call's: ER_ERR_HIP / ER_ERR_OOM with the reason."""
+    lib = abi.load()
     sc = scenes.soup(30000, 120, 88, seed=8, hdri_size=(128, 64))
     ref = gpu_render(sc, 3, max_bounces=8)
     assert _accel(sc, 0)["builder"] == 1
-    monkeypatch.setenv("ER_DEBUG_GPU_BUILD_FAIL", "1")
-    assert _accel(sc, 0)["builder"] == 0
-    got = gpu_render(sc, 3, max_bounces=8)
-    same = (ref["beauty"].view(np.uint32) == got["beauty"].view(np.uint32)).all(-1)
-    assert same.mean() >= 0.9995 and (ref["samples"] == got["samples"]).all()
-    rm = render.RenderingManager(render.RenderParameters(max_bounces=8, flags=abi.FLAG_GPU_BUILD))
-    with pytest.raises(abi.ErError) as e:
-        rm.start_rendering(sc)
-    assert e.value.code == abi.ER_ERR_HIP and "simulated failure" in str(e.value)
-    rm.close()
+    try:
+        for kind, code, loud in ((1, abi.ER_ERR_HIP, True), (2, abi.ER_ERR_OOM, False)):
+            lib.er_debug_set_gpu_build_failure(kind)
+            capfd.readouterr()
+            assert _accel(sc, 0)["builder"] == 0
+            err = capfd.readouterr().err
+            assert ("the device BVH build FAILED" in err) == loud, err
+            got = gpu_render(sc, 3, max_bounces=8)
+            same = (ref["beauty"].view(np.uint32) == got["beauty"].view(np.uint32)).all(-1)
+            assert same.mean() >= 0.9995 and (ref["samples"] == got["samples"]).all()
+            rm = render.RenderingManager(render.RenderParameters(max_bounces=8, flags=abi.FLAG_GPU_BUILD))
+            with pytest.raises(abi.ErError) as e:
+                rm.start_rendering(sc)
+            assert e.value.code == code and "simulated failure" in str(e.value)
+            rm.close()
+    finally:
+        lib.er_debug_set_gpu_build_failure(0)
+    assert _accel(sc, 0)["builder"] == 1
