@@ -503,7 +503,7 @@ def main():
         traffic_source = None
         # HBM-side bytes from rocprofv3 PMC passes of THIS command line (tools/pmc_passes.sh + tools/pmc_traffic.py; counters cannot be
         # collected inside a timed run): replayed, and only for the exact workload they were recorded on
-        standard = args.tris == 1_000_000 and not (args.width or args.height) and not args.max_bounces and world == 1 and shard_world == 1
+        standard = args.tris == 1_000_000 and args.blob_tris == 1000 and not (args.width or args.height) and not args.max_bounces and world == 1 and shard_world == 1
         cfg_key = args.config + ("_nolights" if args.config == "C5" and args.no_lights else "")
         if sched == "stream" and standard:
             for tag in (PROFILE_TAG, "r04"):
@@ -547,6 +547,14 @@ def main():
                          # (wavefront: `traffic` is per trace launch of one pool -- the shade launches' bytes are not in it)
                          "traffic_GBps": round(traffic * (t_launches if sched == "wavefront" else launches) / wall_s / 1e9, 1) if traffic else None,
                          "traffic_frac": round(traffic * (t_launches if sched == "wavefront" else launches) / wall_s / 1e9 / HBM_PEAK_GBS, 4) if traffic else None,
+                         # "L2/MALL-resident traffic must be reported separately from HBM".  What the traversal touches -- wide nodes +
+                         # 48-byte triangle records -- against the 256 MB Infinity Cache: a working set inside it is served by the L2s and that
+                         # cache (FETCH_SIZE, and so `traffic`, counts its hits: MI355X_MICROARCH.md), and "bound: hbm" then names the roofline the
+                         # metric is defined against, not the unit that limits the kernel (the tracer waves' instruction
+                         # streams; profiles/r06_c4_working_set_sweep.log: 57 MB -> 1 147 MB of the same frame costs 19 % of the rate)
+                         "resident": {"traversal_working_set_MB": round((accel["node_count"] * accel["node_bytes"] + 48.0 * scene.tri_count) / 1e6, 1),
+                                      "infinity_cache_MB": 256,
+                                      "where": "inside the Infinity Cache" if accel["node_count"] * accel["node_bytes"] + 48.0 * scene.tri_count <= 256e6 else "beyond the Infinity Cache"},
                          "kernel": kernel_name,
                          "definition": "achieved = all traversal bytes of the timed region (64 B/node visit + 36 B/triangle test, SURVEY 8d) / device time of the region"
                                        + ("; the streaming schedule is ONE kernel (traversal and shading waves side by side): region time = its launch duration, nothing overlaps it" if sched == "stream" else ""),
