@@ -187,7 +187,10 @@ int er_render_begin(ErScene* scene, const ErRenderParams* params);
 /* Adds n samples to every owned pixel. Blocking. Equivalent to n launches of renderingKernel. */
 int er_render_samples(ErScene* scene, uint32_t n);
 /* Non-blocking form + explicit wait; elapsed_ms (may be NULL) = device time of everything
- * enqueued since the previous er_wait, measured with HIP events on the library's stream. */
+ * enqueued since the previous er_wait, measured with HIP events on the library's stream.
+ * (Streaming schedule, the first call of a render with n >= 2: its first sample is a launch of its own that the
+ * call waits for -- the library then decides, from the work counted in it, which screen regions go to which XCD --
+ * before the other n - 1 samples are enqueued: that one call blocks for one sample pass.) */
 int er_render_samples_async(ErScene* scene, uint32_t n);
 int er_wait(ErScene* scene, float* elapsed_ms);
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Record run for profiles/ (one GPU box, repo root):   bash tools/record_run.sh r05 [bench|pmc_c2|pmc_c4|pmc_c5|all]
+# Record run for profiles/ (one GPU box, repo root):   bash tools/record_run.sh r06 [bench|pmc_c2|pmc_c4|pmc_c5|all]
 # (a gpurun call lasts 20 minutes at most: the stages are run as separate calls)
 #   1. the bench line as the driver types it (C2), and rocprofv3 --kernel-trace --stats of the same command;
 #   2. the other BASELINE scenes (C4, C5, C5 without the extensions, C1), one GPU's 1/2, 1/4, 1/8 share of the C2 frame, and the
@@ -9,7 +9,7 @@
 # Afterwards, in the build container:  python tools/pmc_traffic.py gpurun_out/pmc_<tag>_c2 <tag> C2  (and C4, C5),
 #   python tools/pmc_table.py gpurun_out/pmc_<tag>_c2 > profiles/<tag>_pmc_c2_stream_kernel.txt, and copy the logs.
 set -eo pipefail
-tag=${1:-r05}
+tag=${1:-r06}
 stage=${2:-all}
 out=gpurun_out/record_$tag
 mkdir -p $out
