@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-PROFILE_TAG = "r05"     # profiles/<tag>_pmc_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
+PROFILE_TAG = "r06"     # profiles/<tag>_pmc_traffic.json: HBM bytes per launch from the rocprofv3 PMC passes
 
 
 def trace_bytes(c):
