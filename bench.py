@@ -592,6 +592,10 @@ def main():
                         "spread": round((max(rep_values) - min(rep_values)) / max(rep_values[mid], 1e-12), 5),
                         "region_ms": [round(r["kernel_ms"], 3) for r in reps], "elapsed_ms": [round(e * 1e3, 3) for e in rep_elapsed]},
             "readback_ms": round(readback_ms, 2), "gather": gather_path, "beauty_mean": beauty_mean,
+            # the streaming schedule's configuration of this rank's share and its speculation counts over the render (zero on whole frames:
+            # speculative samples exist in the 12-wave form only, i.e. on shares of hardly more pixels than slots)
+            "stream": (lambda si: {"pixels_per_cu": si["pixels_per_cu"], "waves": si["waves"], "tracers": si["tracers"], "large_regions": bool(si["large_regions"]), "lanes_busy": round(si["lanes_busy"], 4),
+                                   "speculation": {"started": si["spec_started"], "right": si["spec_right"], "wrong": si["spec_wrong"]}})(rm.stream_info()) if sched == "stream" else None,
             # N > 1: per-rank device time of the timed region (a rank whose tiles hold longer paths shows here), and the framebuffer
             # combine: wall time of the five er_gather_pass calls on the slowest rank and the bytes the root received
             "ranks": per_rank,
@@ -623,7 +627,10 @@ def main():
                                     # lanes that held a ray in the last launch (the whole frame: roofline.trace_lanes.busy of the instrumented replay),
                                     # the deal; `latency_tracer`: no second tracer role exists (priced and not built)
                                     "pixels_per_cu": si["pixels_per_cu"], "waves": si["waves"], "tracers": si["tracers"], "lanes_busy": round(si["lanes_busy"], 4),
-                                    "large_regions": bool(si["large_regions"]), "latency_tracer": False}
+                                    "large_regions": bool(si["large_regions"]), "latency_tracer": False,
+                                    # round 6: speculative sample pipelining of the 12-wave form: samples started beside the
+                                    # pixel's sample in flight, and how many of those guesses of the RNG state were right / wrong
+                                    "speculation": {"started": si["spec_started"], "right": si["spec_right"], "wrong": si["spec_wrong"]}}
                 except abi.ErError as e:
                     proj[str(n)] = {"error": str(e)}
             result["projected"] = {"what": "one GPU's share (rank 0 of N) of this frame rendered alone on this GPU, median of 3 launches of `steps` steps; "

@@ -472,11 +472,12 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         s->stream_tracers_start = s->stream_tracers; s->stream_low_streak = 0; s->stream_up_budget = 1; s->stream_readings = 0;
         const size_t slots = (size_t)s->stream_blocks * ER_STREAM_SLOTS;
         if ((rc = upload(s->d_wf4, nullptr, slots * er_stream_record_bytes(lights_on) / sizeof(float4), s->stream)) != ER_OK) return rc;
-        if ((rc = upload(s->d_wf1, nullptr, 24, s->stream)) != ER_OK) return rc;       // [1] status word, [2..5] the tracers' lane occupancy, [6..23] start / end per XCD
+        if ((rc = upload(s->d_wf1, nullptr, 32, s->stream)) != ER_OK) return rc;       // [1] status word, [2..5] the tracers' lane occupancy, [6..23] start / end per XCD, [24..26] speculative samples started / right / wrong
         if ((rc = upload(s->d_spill, nullptr, er_stream_spill_entries(s->stream_blocks), s->stream)) != ER_OK) return rc;
         s->stream_ctl = s->d_wf1.p;
         s->stream_lights = lights_on;
-        HIP_TRY(hipMemsetAsync(s->stream_ctl, 0, 24 * sizeof(uint32_t), s->stream));
+        HIP_TRY(hipMemsetAsync(s->stream_ctl, 0, 32 * sizeof(uint32_t), s->stream));
+        s->stream_spec[0] = s->stream_spec[1] = s->stream_spec[2] = 0;
         // the workgroups' pixel rings: (pixel, samples left) entries, one per pixel of the workgroup's share
         // (capacity rounded up to a power of two: positions are monotonic 32-bit counters and may wrap)
         // (no minimum beyond one tile: a producer that comes round to a cell whose entry has not been read yet waits for its
@@ -514,6 +515,8 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
                 s->stream_deal_pending = true;
             }
         }
+        if ((rc = upload(s->d_px_draws, nullptr, npx, s->stream)) != ER_OK) return rc;
+        HIP_TRY(hipMemsetAsync(s->d_px_draws.p, 0, npx * sizeof(uint16_t), s->stream));
         if ((rc = upload(s->d_deal, deal.data(), deal.size(), s->stream)) != ER_OK) return rc;
         HIP_TRY(hipStreamSynchronize(s->stream));          // (`deal` goes out of scope)
         if (s->x_res > 65535u || s->y_res > 65535u)
@@ -643,6 +646,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
     D.owned_tile_count = (uint32_t)owned.size();
     D.counters = s->d_counters.p;
     D.tile_cost = ((s->params.flags & ER_FLAG_STREAM) && s->stream_deal_pending) ? s->d_tile_cost.p : nullptr;
+    D.px_draws = (s->params.flags & ER_FLAG_STREAM) ? s->d_px_draws.p : nullptr;
     {   // the camera's rotation sines / cosines, once, with the functions the device would call (er_math.h: one implementation for both sides)
         const erd::CamTrig t = erd::camera_trig(D.cam);
         D.cam_cx = t.cx; D.cam_sx = t.sx; D.cam_cy = t.cy; D.cam_sy = t.sy; D.cam_cz = t.cz; D.cam_sz = t.sz;
@@ -695,7 +699,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
     }
     if (s->params.flags & ER_FLAG_STREAM) {
         auto launch = [&](uint32_t k) -> int {
-            HIP_TRY(hipMemsetAsync(s->stream_ctl + 2, 0, 22 * sizeof(uint32_t), s->stream));      // the call's lane-occupancy counts, its end per XCD ...
+            HIP_TRY(hipMemsetAsync(s->stream_ctl + 2, 0, 30 * sizeof(uint32_t), s->stream));      // the call's lane-occupancy counts, its end per XCD, its speculation counts ...
             HIP_TRY(hipMemsetAsync(s->stream_ctl + 6, 0xFF, 2 * sizeof(uint32_t), s->stream));    // ... and its start (a minimum)
             if (k > 0) s->stream_launches++;
             er_launch_stream(s->dev, s->d_dev.p, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_deal.p + s->stream_deal_off, s->stream_deal_n, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, k, count,
@@ -787,8 +791,12 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
 // for a finished one.  The word stays set until the next er_render_begin.
 int er_scene_stream_status(ErScene* s, const char* who) {
     if (!(s->params.flags & ER_FLAG_STREAM) || !s->stream_ctl) return ER_OK;
-    uint32_t st[24] = {0};
+    uint32_t st[32] = {0};
     HIP_TRY(hipMemcpy(st, s->stream_ctl, sizeof(st), hipMemcpyDeviceToHost));
+    if (s->stream_spec_seen != s->stream_launches) {      // (once per launch: a read-back after the same launch finds the same words)
+        s->stream_spec_seen = s->stream_launches;
+        for (int k = 0; k < 3; k++) s->stream_spec[k] += st[24 + k];
+    }
     if (st[1] != 0)
         return fail(ER_ERR_STATE, std::string(who) + ": the streaming schedule stopped without finishing (watchdog status " + std::to_string(st[1]) + "); the planes are incomplete");
     const unsigned long long iters = (unsigned long long)st[2] | ((unsigned long long)st[3] << 32), busy = (unsigned long long)st[4] | ((unsigned long long)st[5] << 32);

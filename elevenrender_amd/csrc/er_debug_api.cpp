@@ -275,6 +275,7 @@ static int er_debug_stream_info_impl(ErScene* s, ErStreamInfo* out) {
     out->launches = (uint32_t)s->stream_launches;
     out->pixels_per_cu = (uint32_t)((size_t)s->dev.owned_tile_count * 64 / std::max<uint32_t>(1u, s->stream_blocks));
     out->lanes_busy = s->stream_busy; out->launch_ms = s->stream_launch_ms; out->cost_spread = s->stream_cost_spread;
+    out->spec_started = s->stream_spec[0]; out->spec_right = s->stream_spec[1]; out->spec_wrong = s->stream_spec[2];
     return ER_OK;
 }
 

@@ -98,6 +98,11 @@ struct DevScene {
     // streaming schedule, while the deal of tiles to the XCDs is undecided (er_api.cpp er_stream_adapt): per tile of the frame, the sum
     // of the path lengths of its finished samples -- WORK counted by the kernel, the same on every run of the same frame; NULL = do not count
     uint32_t* tile_cost;
+    // streaming schedule, 12-wave form (er_stream.hip, speculative sample pipelining): per pixel, the draw count its samples are guessed to
+    // have (bits 0-6: how many random numbers a sample draws; 0 = none yet) and a saturating confidence in it (bits 8-10: + 1 for every
+    // accumulated sample that drew that many, - 2 for every other one; at 0 the latest count becomes the guess).  A guess, never a
+    // result: not part of the progressive state (er_state_export), zeroed by er_render_begin
+    uint16_t* px_draws;
 };
 
 // Where pass `pass` of pixel `idx` lives in DevScene::passes.  The four planes a finished sample is accumulated into -- beauty, normal,

@@ -194,8 +194,10 @@ struct ErScene {
     uint32_t stream_low_streak = 0, stream_up_budget = 1, stream_tracers_start = 0, stream_readings = 0;   //   er_stream_adapt: consecutive low readings; steps back up left; the split the render began with
     uint32_t stream_deal_off = 0, stream_deal_n = 0;    //   the deal in use inside d_deal (entries): the one of large super-tiles first, the default edge's after it
     uint32_t stream_deal_alt_off = 0, stream_deal_alt_n = 0;   //   the deal of large screen regions beside it (0 entries: none)
+    uint64_t stream_spec[3] = {0, 0, 0}, stream_spec_seen = 0;   //   speculative samples started / whose guess was right / wrong, summed over the render's completed launches (small shares: er_stream.hip ST_PRED_BIT)
     bool stream_probe_launch = false;                   //   the launch just completed was the first sample of a render's first call, run alone to decide the deal (er_render_samples)
     bool stream_deal_pending = false;                   //   the first completed call decides between the two (er_stream_adapt), from ...
+    DevBuf<uint16_t> d_px_draws;                         //   ... DevScene::px_draws
     DevBuf<uint32_t> d_tile_cost;                       //   ... DevScene::tile_cost: per tile of the frame, the summed path lengths of its finished samples
     std::vector<uint32_t> stream_deal_large;            //   host copy of the large deal until then (which XCD gets which tile under it)
     double stream_cost_spread = -1.0;                   //   (max - min) / mean of the XCDs' counted work under the large deal; < 0: not decided yet
@@ -232,7 +234,7 @@ struct ErScene {
     void release_device() {
         d_nodes.release(); d_nodes8.release(); d_isect.release(); d_attr.release(); d_passes.release(); d_plane.release(); d_materials.release();
         d_textures.release(); d_tex_pool.release(); d_lights.release(); d_cdf.release(); d_samples.release(); d_rng.release();
-        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_deal.release(); d_ray_log.release(); d_mat_fused.release(); d_mat_pre.release(); d_dev.release(); d_tile_cost.release();
+        d_owned.release(); d_counters.release(); d_wf4.release(); d_wf1.release(); d_spill.release(); d_guide.release(); d_ticket.release(); d_deal.release(); d_ray_log.release(); d_mat_fused.release(); d_mat_pre.release(); d_dev.release(); d_tile_cost.release(); d_px_draws.release();
         for (auto& kv : d_rank_tiles) kv.second.release();
         d_rank_tiles.clear();
         d_gather_mine.release();

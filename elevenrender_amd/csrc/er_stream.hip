@@ -252,6 +252,22 @@ struct StState {
     __device__ __forceinline__ float4& aov_b(uint32_t i) const { return fld<float4, 160>(i); }
     __device__ __forceinline__ float4& c_vis(uint32_t i) const { return fld2<float4, 176, 304>(i); }
     __device__ __forceinline__ float4& c_occ(uint32_t i) const { return fld2<float4, 192, 320>(i); }
+    // speculation (SPEC): the verdict word of a speculative slot (SP_*); the local slot + 1 of the speculative sample a slot's sample has started
+    // (0: none); the RNG state a speculative sample assumed; the finish-ring payload a parked speculative slot arrived with; 1 if the
+
+    __device__ __forceinline__ uint32_t& spec_word(uint32_t i) const { return fld<uint32_t, 212>(i); }
+    __device__ __forceinline__ uint32_t& spec_link(uint32_t i) const { return fld<uint32_t, 216>(i); }
+    __device__ __forceinline__ uint32_t& spec_start(uint32_t i) const { return fld<uint32_t, 220>(i); }
+    __device__ __forceinline__ uint32_t& spec_entry(uint32_t i) const { return fld<uint32_t, 224>(i); }
+    // (SPEC) what the sample in the slot has counted so far -- added to the event counters when it is ACCUMULATED, dropped when a wrong guess starts it
+    // over, so that a discarded speculative sample is in no count (the metric's unit is an executed iteration of an accumulated sample):
+    // bounce-loop iterations (bits 0-9) | shaded hits (10-19) | HDRI samples (20-29); rays queued; ER_FLAG_COUNTERS: texels, node visits, triangle tests
+    __device__ __forceinline__ uint32_t& tally_a(uint32_t i) const { return fld<uint32_t, 232>(i); }
+    __device__ __forceinline__ uint32_t& tally_rays(uint32_t i) const { return fld<uint32_t, 236>(i); }
+    __device__ __forceinline__ uint32_t& tally_tex(uint32_t i) const { return fld<uint32_t, 240>(i); }
+    __device__ __forceinline__ uint32_t& tally_nodes(uint32_t i) const { return fld<uint32_t, 244>(i); }
+    __device__ __forceinline__ uint32_t& tally_tris(uint32_t i) const { return fld<uint32_t, 248>(i); }
+
     // the (origin, direction) pair a tracer reads for ray kind 0 / 1 / 2 of slot g: two adjacent 16-byte pieces
     __device__ __forceinline__ const float4* ray_pair(uint32_t g, uint32_t kind) const {
         return (const float4*)(base + (size_t)(g * stride + (kind == 0u ? 0u : (kind == 1u ? 32u : 256u))));
@@ -263,6 +279,21 @@ struct StState {
 // er_bits_release, er_ring.h): a producer that comes round to an unread cell waits for its reader instead of overwriting it.
 #define ST_LAP_TAG(pos, cap) (((((pos) / (cap)) & 0x7Fu) + 1u) << 24)
 #define ST_LEFT_MASK 0x00FFFFFFu
+// Round 6, speculative sample pipelining (the 12-wave form of the kernel = small shares: SPEC).  A pixel's samples are ONE RNG stream
+// (src/kernel.cpp:483-485, 645), so sample k + 1 can start only when sample k has drawn its last number -- unless that number of draws is
+// known beforehand.  It is not, but it can be guessed: the pixels a small share waits for are those whose paths run their full length
+// sample after sample, and a path of h opaque hits draws exactly 5 + 5 h numbers (6 h with the light extension).
+// So when a slot starts a sample of a pixel whose last two accumulated samples drew equally many numbers (DevScene::px_draws) and a slot
+// of the workgroup is free, the pixel's NEXT sample starts at once in that slot, from the state the current one will leave if it
+// draws that many again.  Nothing of a speculative sample reaches the planes before the sample it follows has been accumulated AND has
+// left exactly the state the guess assumed (a compare of two 32-bit states: xorshift32 walks one cycle through all non-zero states,
+// so equal states mean equal streams from there on); after a wrong guess the pixel's next sample starts from the true state as it
+// would have without the guess, and the speculative slot drops what it has.  The image cannot differ, and a dropped sample is in no
+// count (StState::tally_*); what is traded is the work of a path traced for nothing against the chain of a pixel's samples, which
+// is what a small share's launch lasts.
+#define ST_DRAWS_MASK 0x7Fu          // DevScene::px_draws: the guessed draw count of the pixel's samples | confidence in it << ST_CONF_SHIFT (0 .. 7)
+#define ST_CONF_SHIFT 8
+enum { SP_NONE = 0, SP_PENDING = 1, SP_PARKED = 2, SP_VALID = 3, SP_INVALID = 4 };      // StState::spec_word of a speculative slot
 
 // pixel k of workgroup b's share: entry b + (k / 64) * workgroups of the deal (er_stream_deal_tiles below), lane k % 64
 // (false: no tile there, or outside the image)
@@ -283,9 +314,12 @@ __device__ __forceinline__ bool st_pixel_of(const DevScene& S, const uint32_t* d
 __device__ __forceinline__ uint32_t st_pixel_index(const DevScene& S, uint32_t pxy) { return (pxy >> 16) * S.x_res + (pxy & 0xFFFFu); }
 
 // first camera ray of a sample of pixel pxy in slot g (src/kernel.cpp:492-506); the pixel's RNG state comes from its plane
-__device__ __forceinline__ void st_begin_sample(const DevScene& S, const StState& W, uint32_t g, uint32_t pxy, uint32_t left) {
+// (spec: the sample starts from `given` -- a guess of the state the pixel's sample in flight will leave -- instead of the pixel's plane; returns the start state)
+template <bool SPECB>
+__device__ __forceinline__ uint32_t st_begin_sample(const DevScene& S, const StState& W, uint32_t g, uint32_t pxy, uint32_t left, bool spec = false, uint32_t given = 0u) {
     const uint32_t px = pxy & 0xFFFFu, py = pxy >> 16;
-    uint32_t rs = S.rng[py * S.x_res + px];
+    uint32_t rs = spec ? given : S.rng[py * S.x_res + px];
+    const uint32_t rs0 = rs;
     float c1 = rng_next(rs), c2 = rng_next(rs), c3 = rng_next(rs), c4 = rng_next(rs), c5 = rng_next(rs);
     const CamTrig trig = {S.cam_cx, S.cam_sx, S.cam_cy, S.cam_sy, S.cam_cz, S.cam_sz};      // (evaluated once on the host: er_api.cpp)
     const Ray ray = camera_ray(S.cam, (int)px, (int)py, S.x_res, S.y_res, c1, c2, c3, c4, c5, S.cam_trig_valid ? &trig : nullptr);
@@ -298,7 +332,15 @@ __device__ __forceinline__ void st_begin_sample(const DevScene& S, const StState
     W.aov_t(g) = make_float4(0, 0, 0, 0);
     W.aov_b(g) = make_float4(0, 0, 0, 0);
     W.left(g) = left;
+    if (SPECB) {      // (the 16-wave form of the kernel writes none of this: it is the code it was)
+        W.spec_word(g) = spec ? (uint32_t)SP_PENDING : (uint32_t)SP_NONE;
+        W.spec_link(g) = 0u;
+        W.spec_start(g) = given;
+        W.tally_a(g) = 0u; W.tally_rays(g) = 1u;      // (the camera ray)
+        W.tally_tex(g) = 0u; W.tally_nodes(g) = 0u; W.tally_tris(g) = 0u;
+    }
     ER_SP(W.stamp(g) = sp_now(); W.stamp0(g) = W.stamp(g);)
+    return rs0;
 }
 
 // what a finished traversal leaves in the slot's record (closest: winner + second candidate; shadow: verdict + candidates)
@@ -325,6 +367,16 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     // the frame's COST over the XCDs is something only the run can tell (er_api.cpp er_stream_adapt)
     if (threadIdx.x == 0) atomicMin((unsigned long long*)(status + 5), (unsigned long long)wall_clock64());
     constexpr uint32_t RQ_LOG2 = ST_RQ_LOG2, SLOTS = ER_STREAM_SLOTS, TOP_NODES = ER_STREAM_TOP_NODES;
+    // speculative sample pipelining (comment at ST_DRAWS_MASK): compiled into the 12-wave form of the kernel only -- the form er_api.cpp takes for
+    // shares of hardly more pixels than slots, where slots fall free -- and switched by the launch (fin_min's upper bits); the 16-wave
+    // form, which renders whole frames, is the code it was
+    constexpr bool SPEC = ST_THREADS == 768u;
+    bool spec_on = false;
+    uint32_t spec_need = 0;      // the confidence (1 .. 7) a pixel's guess needs for a speculative start; 0 = no speculation
+    uint32_t spec_slack = 0;     // ... and the polls a shader wave must have waited for work before a step in which it may start speculative samples
+    if (SPEC) { spec_need = (fin_min >> 8) & 7u; spec_slack = fin_min >> 12; spec_on = spec_need != 0u && S.px_draws != nullptr; fin_min &= 0xFFu; }
+    __shared__ uint32_t s_free[SPEC ? (1u << ST_SQ_LOG2) : 1u];      // ring of free slots (SPEC): slots whose pixel ring ran dry, and the slots beyond the share's pixels
+    __shared__ __attribute__((aligned(8))) uint32_t s_free_ctl[ER_RING_WORDS];
     __shared__ uint32_t s_rq[1u << RQ_LOG2];
     __shared__ uint32_t s_sq[1u << ST_SQ_LOG2];
     __shared__ uint32_t s_fq[1u << ST_SQ_LOG2];      // finish ring: slots whose path is over and whose sample waits to be accumulated
@@ -349,7 +401,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     for (uint32_t i = threadIdx.x; i < (1u << RQ_LOG2); i += ST_THREADS) s_rq[i] = 0;
     for (uint32_t i = threadIdx.x; i < (1u << ST_SQ_LOG2); i += ST_THREADS) { s_sq[i] = 0; s_fq[i] = 0; }
     for (uint32_t i = threadIdx.x; i < ST_PXBITS_WORDS; i += ST_THREADS) s_pxbits[i] = 0;
+    if (SPEC) for (uint32_t i = threadIdx.x; i < (1u << ST_SQ_LOG2); i += ST_THREADS) s_free[i] = 0;
     if (threadIdx.x < ER_RING_WORDS) { s_rq_ctl[threadIdx.x] = 0; s_sq_ctl[threadIdx.x] = 0; s_px_ctl[threadIdx.x] = 0; s_fq_ctl[threadIdx.x] = 0; }
+    if (SPEC && threadIdx.x < ER_RING_WORDS) s_free_ctl[threadIdx.x] = 0;
     if (threadIdx.x < C_WORDS) s_ctl[threadIdx.x] = 0;
     __syncthreads();
     // this workgroup's pixels in the order of its tiles: the first SLOTS valid ones start in the slots, the others
@@ -366,7 +420,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
         const bool to_slot = valid && v < SLOTS;
         const uint32_t idx = ST_PXY(px, py);
         if (to_slot) {
-            st_begin_sample(S, W, g0 + v, idx, n_samples);
+            st_begin_sample<(ST_THREADS == 768u)>(S, W, g0 + v, idx, n_samples);
             s_wait[v] = 1u;
         } else if (valid) {
             const uint32_t pos = v - SLOTS;      // (< ring_cap: lap 0 of a ring nobody reads yet)
@@ -390,10 +444,18 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_ctl[C_LIVE] == 0) s_ctl[C_DONE] = 1;
+    if (SPEC && spec_on) {      // the slots no pixel started in are free from the beginning
+        const uint32_t nv = s_ctl[C_INIT], started = nv < SLOTS ? nv : SLOTS;
+        for (uint32_t s0 = 0; s0 < SLOTS; s0 += ST_THREADS) {
+            const uint32_t sl = s0 + threadIdx.x;
+            st_push<ST_SQ_LOG2>(s_free, s_free_ctl, sl < SLOTS && sl >= started && n_samples > 0, sl, status, ST_ERR_SHADE);
+        }
+    }
 
     unsigned c_rays = 0, c_nodes = 0, c_tris = 0;
     unsigned c_paths = 0, c_bounce = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;
     unsigned c_wsteps = 0, c_busy = 0, c_nl = 0, c_tl = 0;
+    unsigned c_spec[3] = {0, 0, 0};      // (SPEC) speculative samples started / guesses right / wrong
 
     {
         __shared__ uint2 s_stack[ST_MAX_TRACERS * WF_LDS_STACK * 64];
@@ -409,6 +471,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
 #if ER_TRACER_PRIO
             __builtin_amdgcn_s_setprio(ER_TRACER_PRIO);
 #endif
+            unsigned ray_n0 = 0, ray_t0 = 0;      // (SPEC && COUNT) the lane's visit / test counts when it took its ray
             uint32_t lsk = 0;      // the ray in hand: its ray-ring payload, local slot | kind << 11 (ONE register across the traversal; the
                                    // record index g0 + slot (+ W.slots for a point-light query) is recomputed where it is needed)
             uint32_t idle = 0, progress = 0;
@@ -435,6 +498,11 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
 #endif
                     const uint32_t ls = lsk & ST_SLOT_MASK, kind = lsk >> ST_SLOT_BITS;
                     if (done) st_write_result(W, g0 + ls + (kind == 2u ? W.slots : 0u), T.shadow, done_occl, T.overflow, T.s0, T.s1);
+                    if (SPEC && COUNT && done) {      // this ray's visits and tests belong to its sample (counted if and when that is accumulated)
+                        atomicAdd(&W.tally_nodes(g0 + ls), c_nodes - ray_n0);
+                        atomicAdd(&W.tally_tris(g0 + ls), c_tris - ray_t0);
+                        c_nodes = ray_n0; c_tris = ray_t0;
+                    }
                     ER_SP(if (done && kind == 0u) { const uint32_t spD = sp_now(); sAB += spB - spA; sBC += spC - spB; sCD += spD - spC; sN++; W.stamp(g0 + ls) = spD; })
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                     bool last = false;
@@ -479,7 +547,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                             const float4 rd = shadow ? W.sh_d(rec) : W.ray_d(rec);
                             trav_begin(T, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), shadow, shadow ? __builtin_bit_cast(int, ro.w) : -1,
                                        shadow ? rd.w : __builtin_inff());
-                            c_rays++;
+                            if (!SPEC) c_rays++;      // (SPEC: counted where the ray is queued, into its sample's tally)
+                            if (SPEC && COUNT) { ray_n0 = c_nodes; ray_t0 = c_tris; }
                             busy = true;
                             ER_SP(if (kind == 0u) { spA = W.stamp(rec); spB = sp_now(); })
                         }
@@ -600,6 +669,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
         bool have = false;
         uint32_t e = 0;
         uint32_t idle = 0, spins = 0, progress = 0;
+        uint32_t slack = 0;
         ER_SP(uint32_t sDE = 0; uint32_t sEF = 0; uint32_t sGE = 0; uint32_t sNG = 0; uint32_t sSS = 0; uint32_t sNS = 0;)
 #if ER_SHADER_PRIO
         __builtin_amdgcn_s_setprio(ER_SHADER_PRIO);      // (static priority for the whole loop: issue arbitration is by priority, then age)
@@ -617,6 +687,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 __builtin_amdgcn_s_sleep(ST_IDLE_SLEEP);
                 const uint32_t pr = er_ring_load(&s_rq_ctl[ER_RING_TAIL]) + er_ring_load(&s_sq_ctl[ER_RING_TAIL]) + er_ring_load(&s_fq_ctl[ER_RING_TAIL]);
                 if (pr != progress) { progress = pr; idle = 0; }
+                if (SPEC) slack++;
                 if (++idle > ST_WATCHDOG) {
                     if (lane == 0) { atomicOr(status, 2u); s_ctl[C_DONE] = 1; }
                     break;
@@ -638,11 +709,14 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 if (favail > 0 && (avail == 0 || spins >= patience / 3u)) fin_mode = true;
                 else if (spins < patience) {     // a fuller batch costs the same instructions: wait a little for one
                     spins++;
+                    if (SPEC) slack++;
                     __builtin_amdgcn_s_sleep(ST_BATCH_SLEEP);
                     continue;
                 }
             }
             spins = 0;
+            const uint32_t waited = slack;      // (SPEC) polls this wave spent waiting for work since its last step: the shader waves' slack
+            slack = 0;
             ER_MARK("shader_take");
             ER_TPS(0);
             uint32_t hb = 0;
@@ -656,12 +730,42 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
             const uint32_t slot = g0 + ls;
             bool want_pixel = false, to_finish = false;
             uint32_t rs = 0, left_after = 0, done_idx = 0;
+            // speculation (SPEC): this lane's sample continues in a speculative slot / wakes a parked speculative slot with this finish-ring entry /
+            // has started a speculative sample in local slot ls_spec whose camera ray is to be queued
+            bool has_spec = false, wake = false, push_spec = false;
+            uint32_t wake_entry = 0, ls_spec = 0;
             ER_MARK("shader_step");
             ER_TPS(1);
             ER_SP(uint32_t spE = 0;)
             ER_SP(if (have) { spE = sp_now(); if (fin_mode ? (e >> ST_SLOT_BITS) != 0 : (e >> ST_SLOT_BITS) == 0) sDE += spE - W.stamp(slot);
                               else if (fin_mode) { sGE += spE - W.stamp(slot); sNG++; } })
-            if (have && !fin_mode) {
+            bool parked = false, discard = false;
+            if (SPEC && spec_on && fin_mode && have) {
+                // a SPECULATIVE sample reaches its finishing step: nothing of it may reach the planes before the sample it follows has been
+                // accumulated and has left the state this one assumed.  Verdict there: commit, or start over from the true state.  Not yet:
+                // the slot parks (one compare-and-swap against the committing slot's exchange: exactly one of the two moves it on)
+                uint32_t sw = __hip_atomic_load(&W.spec_word(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (sw != (uint32_t)SP_NONE) {
+                    if (sw == (uint32_t)SP_PENDING) {
+                        W.spec_entry(slot) = e;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        sw = atomicCAS(&W.spec_word(slot), (uint32_t)SP_PENDING, (uint32_t)SP_PARKED);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    parked = sw == (uint32_t)SP_PENDING;
+                    discard = sw == (uint32_t)SP_INVALID;
+                    if (!parked) W.spec_word(slot) = (uint32_t)SP_NONE;      // (from here on an ordinary sample: committed below, or started over)
+                }
+            }
+            // A speculative sample whose guess was wrong is dropped where it stands -- at its next shading step or at its finishing step -- and its
+            // slot falls free: the pixel's sample has been started over, from the true state, by the slot that wrote the verdict (so a wrong
+            // guess costs the work of a path, never time in the chain of the pixel's samples)
+            bool cancel = false;
+            if (SPEC && spec_on && have && !fin_mode) cancel = __hip_atomic_load(&W.spec_word(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (uint32_t)SP_INVALID;
+            if (SPEC && (discard || cancel)) retire = true;
+            // (SPEC) what this step counts goes to the slot's tally, not to the lane's accumulators: it is counted when the sample is accumulated
+            const unsigned k_b0 = c_bounce, k_sh0 = c_shaded, k_hd0 = c_hdri, k_tx0 = c_texels, k_nd0 = c_nodes, k_tr0 = c_tris;
+            if (have && !fin_mode && !cancel) {
                 const bool fin_only = (e >> ST_SLOT_BITS) != 0;
                 float4 L4 = W.light(slot), R4 = W.reduc(slot);
                 F3 light = f3(L4.x, L4.y, L4.z), reduction = f3(R4.x, R4.y, R4.z);
@@ -755,12 +859,22 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                     s_wait[ls] = (push_closest ? 1u : 0u) + (push_shadow ? 1u : 0u) + (push_light ? 1u : 0u) + (fin_next ? ST_FIN : 0u);
                 }
             }
+            if (SPEC && have && !fin_mode && !cancel) {
+                W.tally_a(slot) += (c_bounce - k_b0) | ((c_shaded - k_sh0) << 10) | ((c_hdri - k_hd0) << 20);
+                W.tally_rays(slot) += (push_closest ? 1u : 0u) + (push_shadow ? 1u : 0u) + (push_light ? 1u : 0u);
+                if (COUNT) {
+                    W.tally_tex(slot) += c_texels - k_tx0;
+                    atomicAdd(&W.tally_nodes(slot), c_nodes - k_nd0);      // (the tracers add to these two as well)
+                    atomicAdd(&W.tally_tris(slot), c_tris - k_tr0);
+                }
+                c_bounce = k_b0; c_shaded = k_sh0; c_hdri = k_hd0; c_texels = k_tx0; c_nodes = k_nd0; c_tris = k_tr0;
+            }
             if (!fin_mode) {
                 if (__ballot(to_finish)) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the record first, then the entry
                     st_push<ST_SQ_LOG2>(s_fq, s_fq_ctl, to_finish, ls, status, ST_ERR_SHADE);
                 }
-            } else if (have) {
+            } else if (have && !parked && !discard) {
                 ER_TPS(6);
                 const uint32_t pxy = W.pix(slot);
                 const uint32_t idx = st_pixel_index(S, pxy);
@@ -811,6 +925,44 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 if (sa2 != sa) S.samples[idx] = sa2;
                 S.rng[idx] = rs;
                 c_paths++;
+                if (SPEC) {      // the accumulated sample's own counts (this step's part -- a path that left the scene -- was counted above, directly)
+                    const uint32_t ta = W.tally_a(slot);
+                    c_bounce += ta & 0x3FFu; c_shaded += (ta >> 10) & 0x3FFu; c_hdri += (ta >> 20) & 0x3FFu;
+                    c_rays += W.tally_rays(slot);
+                    if (COUNT) { c_texels += W.tally_tex(slot); c_nodes += W.tally_nodes(slot); c_tris += W.tally_tris(slot); }
+                }
+                if (SPEC && spec_on) {
+                    {   // the pixel's next guess: what this sample drew -- 5 for the camera ray, then per iteration that hit: 1 (opacity) + 4 for an opaque
+                        // one (HDRI cell, three for the BRDF sample), 5 with the light extension (src/kernel.cpp:492-493, 538-545; er_bounce.inc)
+                        const uint32_t ta = W.tally_a(slot);
+                        const uint32_t per_opaque = (EXT && (S.ext_flags & ER_FLAG_POINT_LIGHTS) != 0 && S.light_count > 0) ? 5u : 4u;
+                        uint32_t nd = 5u + ((ta >> 10) & 0x3FFu) + per_opaque * ((ta >> 20) & 0x3FFu);
+                        nd = nd > ST_DRAWS_MASK ? 0u : nd;      // (longer than the field: no guess for this pixel)
+                        // a saturating counter per pixel, as a branch predictor keeps one per branch: the guess stays while it is mostly right
+                        const uint32_t oldh = S.px_draws[idx];
+                        uint32_t cand = oldh & ST_DRAWS_MASK, conf = oldh >> ST_CONF_SHIFT;
+                        if (nd != 0u && nd == cand) conf = conf < 7u ? conf + 1u : 7u;
+                        else if (conf >= 2u) conf -= 2u;
+                        else { cand = nd; conf = nd != 0u ? 1u : 0u; }
+                        S.px_draws[idx] = (uint16_t)(cand | (conf << ST_CONF_SHIFT));
+                    }
+                    const uint32_t link = W.spec_link(slot);
+                    if (link) {
+                        // this sample started a speculative successor: its guess was right iff this sample left exactly the state it assumed
+                        const uint32_t f = g0 + link - 1u;
+                        const bool ok = W.spec_start(f) == rs;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the planes and the RNG state first, then the verdict
+                        const uint32_t old = atomicExch(&W.spec_word(f), ok ? (uint32_t)SP_VALID : (uint32_t)SP_INVALID);
+                        c_spec[ok ? 1 : 2]++;      // (statistics: guesses right / wrong)
+                        if (old == (uint32_t)SP_PARKED) {      // it has finished its path and waits: this lane puts it back on the finish ring
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                            wake = true;
+                            wake_entry = W.spec_entry(f);
+                        }
+                        has_spec = ok;      // right: the pixel goes on in that slot, no entry in the pixel ring.  Wrong: the pixel goes back to the ring as after any
+                                            // sample (this slot, or the next free one, starts its next sample from the true state); the other slot drops what it has
+                    }
+                }
                 ER_SP(sSS += sp_now() - W.stamp0(slot); sNS++;)
                 // the sample is done: the pixel goes back to the ring (below, as a wave) and the slot takes the next one
                 left_after = W.left(slot) - 1;
@@ -821,7 +973,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
             ER_TPS(7);
             // finished samples: pixel back to the tail of the pixel ring (unless that was its last sample), next pixel from the head
             if (__ballot(want_pixel)) {
-                const bool back = want_pixel && left_after > 0;
+                const bool back = want_pixel && left_after > 0 && !has_spec;
                 const unsigned long long mb = __ballot(back);
                 if (mb) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the pixel's planes and RNG state first, then its entry
@@ -838,6 +990,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 }
                 // take up to `want` entries (exact count: a slot that has just put its pixel back always finds an entry unless
                 // another slot has taken it)
+                bool spawn_want = false;
+                uint32_t spawn_rs = 0, spawn_pxy = 0, spawn_left = 0, spawn_draws = 0;
                 const unsigned long long mw = __ballot(want_pixel);
                 uint32_t hb2 = 0;
                 const uint32_t granted2 = st_take(s_px_ctl, (uint32_t)__popcll(mw), hb2, er_ring_peek(s_px_ctl));
@@ -862,7 +1016,16 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                     const uint32_t nidx = (uint32_t)w;
                     y &= ST_LEFT_MASK;
                     if (y != 0) {
-                        st_begin_sample(S, W, slot, nidx, y);
+                        spawn_rs = st_begin_sample<SPEC>(S, W, slot, nidx, y);
+                        if (SPEC && spec_on && y > 1u) {
+                            const uint32_t h = S.px_draws[st_pixel_index(S, nidx)];
+                            spawn_draws = h & ST_DRAWS_MASK;
+                            // (... and only from a shader wave that has been WAITING for work: where the shader waves never wait another sample in
+                            // flight adds to their queue, not to the pixel's progress -- C1's 12-triangle box is bound by its three shader waves and
+                            // ran 9 % slower with every pixel two samples deep)
+                            spawn_want = spawn_draws != 0u && (h >> ST_CONF_SHIFT) >= spec_need && waited >= spec_slack;
+                        }
+                        spawn_pxy = nidx; spawn_left = y - 1u;
                         s_wait[ls] = 1u;
                         push_closest = true;
                     } else {
@@ -872,6 +1035,39 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 } else if (want_pixel) {
                     retire = true;      // nothing left in the ring: the pixels still unfinished are all in flight in other slots
                 }
+                if (SPEC && spec_on && __ballot(spawn_want)) {
+                    // the samples just begun whose pixels' last samples drew equally many numbers: where a slot is free, the pixel's next sample starts
+                    // in it at once, from the state this one leaves if it draws as many numbers as the pixel's last one did
+                    const unsigned long long msp = __ballot(spawn_want);
+                    uint32_t hbf = 0;
+                    const uint32_t gf = st_take(s_free_ctl, (uint32_t)__popcll(msp), hbf, er_ring_peek(s_free_ctl));
+                    const uint32_t rk = (uint32_t)__popcll(msp & below);
+                    uint32_t fslot = 0;
+                    bool got_free = false;
+                    if (spawn_want && rk < gf) {
+                        got_free = er_ring_get(s_free, ST_SQ_LOG2, hbf + rk, fslot);
+                        if (!got_free) atomicOr(status, ST_ERR_SHADE);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (got_free) {
+                        uint32_t sp = spawn_rs;
+                        for (uint32_t k = 0; k < spawn_draws; k++) { sp ^= sp << 13; sp ^= sp >> 17; sp ^= sp << 5; }      // (rng_next's step, src/kernel.cpp:42-47)
+                        st_begin_sample<SPEC>(S, W, g0 + fslot, spawn_pxy, spawn_left, true, sp);
+                        W.spec_link(slot) = fslot + 1u;
+                        s_wait[fslot] = 1u;
+                        push_spec = true;
+                        ls_spec = fslot;
+                    }
+                    const unsigned long long mgot = __ballot(got_free);
+                    if (mgot && lane == (int)(__ffsll((long long)mgot) - 1)) {
+                        atomicAdd(&s_ctl[C_LIVE], (uint32_t)__popcll(mgot));      // before any slot of this step retires
+                    }
+                    if (got_free) c_spec[0]++;      // (statistics: speculative samples started; flushed once per wave at the end)
+                }
+            }
+            if (SPEC && spec_on && __ballot(wake)) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                st_push<ST_SQ_LOG2>(s_fq, s_fq_ctl, wake, wake_entry, status, ST_ERR_SHADE);      // the parked speculative slots whose verdict this step has written
             }
             ER_MARK("shader_publish");
             ER_TPS(8);
@@ -879,7 +1075,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             {
                 const unsigned long long mc = __ballot(push_closest), ms = __ballot(push_shadow), ml = EXT ? __ballot(push_light) : 0ull;
-                const unsigned nc = (unsigned)__popcll(mc), ns = (unsigned)__popcll(ms), nl = (unsigned)__popcll(ml);
+                const unsigned long long mx = SPEC ? __ballot(push_spec) : 0ull;
+                const unsigned nc = (unsigned)__popcll(mc), ns = (unsigned)__popcll(ms), nl = (unsigned)__popcll(ml) + (unsigned)__popcll(mx);
                 ER_SP(if (push_closest) { const uint32_t spF = sp_now(); sEF += spF - spE; W.stamp(slot) = spF; })
                 if (nc + ns + nl) {
                     uint32_t base = 0;
@@ -889,10 +1086,12 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                     if (push_closest) ok = er_ring_put(s_rq, RQ_LOG2, base + (uint32_t)__popcll(mc & below), ls) && ok;
                     if (push_shadow) ok = er_ring_put(s_rq, RQ_LOG2, base + nc + (uint32_t)__popcll(ms & below), ls | (1u << ST_SLOT_BITS)) && ok;
                     if (EXT && push_light) ok = er_ring_put(s_rq, RQ_LOG2, base + nc + ns + (uint32_t)__popcll(ml & below), ls | (2u << ST_SLOT_BITS)) && ok;
+                    if (SPEC && push_spec) ok = er_ring_put(s_rq, RQ_LOG2, base + nc + ns + (uint32_t)__popcll(ml) + (uint32_t)__popcll(mx & below), ls_spec) && ok;
                     if (!ok) atomicOr(status, ST_ERR_RAY);
                     if (lane == 0) er_ring_publish(s_rq_ctl, nc + ns + nl);      // (after the cells: LDS is in order per wave)
                 }
                 const unsigned long long mr = __ballot(retire);
+                if (SPEC && spec_on && mr) st_push<ST_SQ_LOG2>(s_free, s_free_ctl, retire, ls, status, ST_ERR_SHADE);      // a slot without a pixel is free for a speculative sample
                 if (mr) {
                     const uint32_t nr = (uint32_t)__popcll(mr);
                     if (lane == 0) {
@@ -925,6 +1124,10 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     }
     return;
 #endif
+    if (SPEC) {
+        const unsigned q0 = st_wave_sum(c_spec[0]), q1 = st_wave_sum(c_spec[1]), q2 = st_wave_sum(c_spec[2]);
+        if (lane == 0 && (q0 | q1 | q2)) { atomicAdd(status + 23, q0); atomicAdd(status + 24, q1); atomicAdd(status + 25, q2); }
+    }
     unsigned t0 = st_wave_sum(c_paths), t1 = st_wave_sum(c_bounce), t2 = st_wave_sum(c_rays), t3 = st_wave_sum(c_shaded), t4 = st_wave_sum(c_hdri);
     unsigned t5 = 0, t6 = 0, t7 = 0;
     if (COUNT) { t5 = st_wave_sum(c_nodes); t6 = st_wave_sum(c_tris); t7 = st_wave_sum(c_texels); }
@@ -1030,7 +1233,17 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
         int v = e ? atoi(e) : 64;      // (a finishing step runs as soon as it is full)
         return (uint32_t)(v < 1 ? 1 : (v > 64 ? 64 : v));
     }();
+    // speculative sample pipelining (12-wave form).  ER_STREAM_SPEC: 0 = off, 1 .. 7 = the confidence a pixel's guessed draw count needs (A/B knob)
+    static const uint32_t spec_flag = [] {
+        const char* e = getenv("ER_STREAM_SPEC");
+        const char* b = getenv("ER_STREAM_SPEC_SLACK");      // polls a shader wave must have waited before a step that starts speculative samples (knob; 0 = no condition)
+        int v = e ? atoi(e) : 2, bl = b ? atoi(b) : 1;
+        return ((uint32_t)(v < 0 ? 0 : (v > 7 ? 7 : v)) << 8) | ((uint32_t)(bl < 0 ? 0 : (bl > 4096 ? 4096 : bl)) << 12);
+    }();
     if (S.owned_tile_count == 0 || n_samples == 0) return;
+    // (a slot's tally keeps its iterations in ten bits; and a scene of a few triangles -- C1's 12-triangle box, 256 pixels per CU -- runs 5-9 % SLOWER two
+    // samples deep, right guesses and all: its rays are three traversal steps long and there is nothing to overlap, profiles/r06_ab_speculative_samples.log)
+    const uint32_t spec_now = (S.max_bounces <= 1000u && S.tri_count >= ER_STREAM_SPEC_MIN_TRIS) ? spec_flag : 0u;
     if (tracers > ST_MAX_TRACERS) tracers = ST_MAX_TRACERS;      // (the LDS traversal stacks are sized for that many; at least 3 shader waves stay)
     waves = waves == 12u ? 12u : 16u;
     if (tracers > waves - 1u) tracers = waves - 1u;      // at least one shader wave
@@ -1049,7 +1262,7 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
     st.slots = slots;
     st.stride = er_stream_record_bytes(lights);
     const DevScene __attribute__((address_space(4)))* dS = (const DevScene __attribute__((address_space(4)))*)S_dev;
-    if (waves == 12u) hipLaunchKernelGGL(k12, dim3(blocks), dim3(768), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
+    if (waves == 12u) hipLaunchKernelGGL(k12, dim3(blocks), dim3(768), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min | spec_now);
     else hipLaunchKernelGGL(k16, dim3(blocks), dim3(1024), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
 }
 

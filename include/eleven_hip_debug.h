@@ -112,6 +112,7 @@ typedef struct ErStreamInfo {
     double lanes_busy;             /* share of the tracer waves' lanes that held a ray, last completed launch */
     double launch_ms;              /* device time of that launch */
     double cost_spread;            /* (max - min) / mean of the XCDs' counted work under the large deal; < 0: not decided */
+    uint64_t spec_started, spec_right, spec_wrong;   /* speculative samples (small shares) started / whose guessed RNG state was right / wrong, completed launches of this render */
 } ErStreamInfo;
 int er_debug_stream_info(struct ErScene* s, ErStreamInfo* out);
 
