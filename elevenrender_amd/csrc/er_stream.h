@@ -34,6 +34,9 @@ struct WfState;
 #ifndef ER_STREAM_SMALL_SHARE
 #define ER_STREAM_SMALL_SHARE 1152u  // owned pixels per CU up to which a workgroup runs as 12 waves of 168 registers (9 tracers + 3 shaders) instead of 16 of 128
 #endif
+#ifndef ER_STREAM_SPEC_SHARE
+#define ER_STREAM_SPEC_SHARE 2304u   // owned pixels per CU up to which the kernel's form with speculative samples is launched (`spec`; the 12-wave form always is)
+#endif
 #ifndef ER_STREAM_SPEC_MIN_TRIS
 #define ER_STREAM_SPEC_MIN_TRIS 1000u   // scenes of fewer triangles never start speculative samples (er_stream.hip ST_DRAWS_MASK; C1: -9 % with them)
 #endif
@@ -50,7 +53,7 @@ struct WfState;
 // a wave of XCD x = workgroup index % 8 (caller: zero), wall_clock64() ticks.
 // S_dev: a device copy of S (the kernel reads the scene descriptor from constant memory, not from its arguments).
 void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
-                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, hipStream_t stream);
+                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, bool spec, hipStream_t stream);
 // the deal of the owned tiles to the workgroups (device copy of `out` = `deal` above, deal_count = out.size()); returns the most tiles of one workgroup
 // edge: side of a super-tile in 8 x 8 tiles; 0 = ER_STREAM_SUPER_TILE from the environment, else ER_STREAM_SUPER_TILE_DEFAULT
 uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, bool xcd_aware, std::vector<uint32_t>& out, uint32_t edge = 0);

@@ -357,7 +357,7 @@ __device__ __forceinline__ void st_write_result(const StState& W, uint32_t rec, 
 
 }  // namespace
 
-template <bool COUNT, bool EXT, uint32_t ST_THREADS, bool FUSE>
+template <bool COUNT, bool EXT, uint32_t ST_THREADS, bool FUSE, bool SPECT>
 __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __attribute__((address_space(4)))* Sp, StState W, const uint32_t* deal, uint32_t deal_count, uint2* ring_base, uint32_t ring_cap,
                                                           uint32_t* status, uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min, uint32_t fin_min) {
     // The scene descriptor lives in constant memory and is read with scalar loads where it is used.  As a by-value kernel argument its
@@ -367,10 +367,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     // the frame's COST over the XCDs is something only the run can tell (er_api.cpp er_stream_adapt)
     if (threadIdx.x == 0) atomicMin((unsigned long long*)(status + 5), (unsigned long long)wall_clock64());
     constexpr uint32_t RQ_LOG2 = ST_RQ_LOG2, SLOTS = ER_STREAM_SLOTS, TOP_NODES = ER_STREAM_TOP_NODES;
-    // speculative sample pipelining (comment at ST_DRAWS_MASK): compiled into the 12-wave form of the kernel only -- the form er_api.cpp takes for
-    // shares of hardly more pixels than slots, where slots fall free -- and switched by the launch (fin_min's upper bits); the 16-wave
-    // form, which renders whole frames, is the code it was
-    constexpr bool SPEC = ST_THREADS == 768u;
+    // speculative sample pipelining (comment at ST_DRAWS_MASK): a template argument -- the instances that render whole frames (SPECT = false: no slot
+    // ever falls free while pixels wait in the ring) are the code they were; er_launch_stream takes a SPECT instance for shares of few pixels per slot
+    constexpr bool SPEC = SPECT;
     bool spec_on = false;
     uint32_t spec_need = 0;      // the confidence (1 .. 7) a pixel's guess needs for a speculative start; 0 = no speculation
     uint32_t spec_slack = 0;     // ... and the polls a shader wave must have waited for work before a step in which it may start speculative samples
@@ -420,7 +419,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
         const bool to_slot = valid && v < SLOTS;
         const uint32_t idx = ST_PXY(px, py);
         if (to_slot) {
-            st_begin_sample<(ST_THREADS == 768u)>(S, W, g0 + v, idx, n_samples);
+            st_begin_sample<SPEC>(S, W, g0 + v, idx, n_samples);
             s_wait[v] = 1u;
         } else if (valid) {
             const uint32_t pos = v - SLOTS;      // (< ring_cap: lap 0 of a ring nobody reads yet)
@@ -1153,8 +1152,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
 hipError_t er_probe_stream(const char** which) {
     hipFuncAttributes a;
     *which = "er_stream_kernel";
-    hipError_t e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 1024u, false>);
-    return e != hipSuccess ? e : hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 768u, true>);
+    hipError_t e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 1024u, false, false>);
+    return e != hipSuccess ? e : hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 768u, true, true>);
 }
 
 // Which workgroup renders which tiles.  Workgroups b and b + 8 run on the same XCD and share its 4 MB L2 (observed dispatch
@@ -1212,7 +1211,7 @@ uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t ti
 }
 
 void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
-                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, hipStream_t stream) {
+                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, bool spec, hipStream_t stream) {
     static const uint32_t refill_min = [] {
         const char* e = getenv("ER_STREAM_REFILL_MIN");
         int v = e ? atoi(e) : 12;
@@ -1252,10 +1251,16 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
     // (FUSE: an instance without the fused-texel path for scenes in which no material is fused, er_device.h generate_hit_data)
     const bool fuse = S.fused_any != 0u;
     auto pick = [&](auto with, auto without) { return fuse ? with : without; };
-    auto k16 = count ? (ext ? pick(er_stream_kernel<true, true, 1024u, true>, er_stream_kernel<true, true, 1024u, false>) : pick(er_stream_kernel<true, false, 1024u, true>, er_stream_kernel<true, false, 1024u, false>))
-                     : (ext ? pick(er_stream_kernel<false, true, 1024u, true>, er_stream_kernel<false, true, 1024u, false>) : pick(er_stream_kernel<false, false, 1024u, true>, er_stream_kernel<false, false, 1024u, false>));
-    auto k12 = count ? (ext ? pick(er_stream_kernel<true, true, 768u, true>, er_stream_kernel<true, true, 768u, false>) : pick(er_stream_kernel<true, false, 768u, true>, er_stream_kernel<true, false, 768u, false>))
-                     : (ext ? pick(er_stream_kernel<false, true, 768u, true>, er_stream_kernel<false, true, 768u, false>) : pick(er_stream_kernel<false, false, 768u, true>, er_stream_kernel<false, false, 768u, false>));
+    // instances: counters x extensions x fused textures, in three forms: 16 waves (whole frames), 16 waves with speculative samples, 12 waves with them
+#define ST_PICK(THREADS, SPECV)                                                                                                                                  \
+    (count ? (ext ? pick(er_stream_kernel<true, true, THREADS, true, SPECV>, er_stream_kernel<true, true, THREADS, false, SPECV>)                                 \
+                  : pick(er_stream_kernel<true, false, THREADS, true, SPECV>, er_stream_kernel<true, false, THREADS, false, SPECV>))                               \
+           : (ext ? pick(er_stream_kernel<false, true, THREADS, true, SPECV>, er_stream_kernel<false, true, THREADS, false, SPECV>)                               \
+                  : pick(er_stream_kernel<false, false, THREADS, true, SPECV>, er_stream_kernel<false, false, THREADS, false, SPECV>)))
+    auto k16 = ST_PICK(1024u, false);
+    auto k16s = ST_PICK(1024u, true);
+    auto k12 = ST_PICK(768u, true);
+#undef ST_PICK
     StState st;
     st.base = (char*)records;
     st.spill = (uint2*)spill;
@@ -1263,6 +1268,7 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
     st.stride = er_stream_record_bytes(lights);
     const DevScene __attribute__((address_space(4)))* dS = (const DevScene __attribute__((address_space(4)))*)S_dev;
     if (waves == 12u) hipLaunchKernelGGL(k12, dim3(blocks), dim3(768), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min | spec_now);
+    else if (spec && spec_now) hipLaunchKernelGGL(k16s, dim3(blocks), dim3(1024), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min | spec_now);
     else hipLaunchKernelGGL(k16, dim3(blocks), dim3(1024), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
 }
 

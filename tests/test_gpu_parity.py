@@ -644,3 +644,40 @@ def test_scalar_only_textures_kept_with_one_channel_do_not_change_the_image(orac
         assert (compact[p].view(np.uint32) == as_is[p].view(np.uint32)).all(), p
     assert (compact["rng"] == as_is["rng"]).all()
     compare(compact, oracle_render(oracle_mod, sc, 5, max_bounces=8), what="scalar-only textures with one channel")
+
+
+@pytest.mark.parametrize("waves", ["12", "16"])
+@pytest.mark.parametrize("ext", [0, abi.FLAG_POINT_LIGHTS | abi.FLAG_MIS])
+def test_speculative_samples_change_neither_the_image_nor_any_count(waves, ext, monkeypatch):
+    """Round 6: on shares of few pixels per slot the streaming kernel starts a pixel's NEXT sample beside the one in flight, from the RNG
+    state that one will leave if it draws as many numbers as the pixel's samples have been drawing (csrc/er_stream.hip, ST_DRAWS_MASK).  A
+    speculative sample is accumulated only after its predecessor, and only if the predecessor left exactly the guessed state; otherwise
+    it is dropped and the pixel's next sample starts from the true state.  So the planes, the sample counts, the RNG states AND every
+    event counter -- paths, bounce-loop iterations (the metric's unit), rays, shaded hits, HDRI samples, and with ER_FLAG_COUNTERS node
+    visits and triangle tests -- must equal those of the wavefront schedule, which knows no speculation; and the guesses must have
+    happened: both right and wrong ones (a frame of 40 x 30 tiles on 256 workgroups: 300 pixels per CU, 724 free slots each)."""
+    sc = scenes.soup(30000, 320, 240, seed=17, hdri_size=(128, 64))
+    if ext:
+        sc.point_lights = scenes.point_lights(12, seed=4)
+        sc._desc = None
+    monkeypatch.setenv("ER_STREAM_WAVES", waves)
+    monkeypatch.setenv("ER_STREAM_SPEC_FORM", "1")
+    for count in (0, abi.FLAG_COUNTERS):
+        w = gpu_render(sc, 24, max_bounces=8, flags=abi.FLAG_WAVEFRONT | ext | count)
+        rm = render.RenderingManager(render.RenderParameters(max_bounces=8, flags=abi.FLAG_STREAM | ext | count))
+        rm.start_rendering(sc)
+        for n in (5, 19):
+            rm.render(n)
+        si = rm.stream_info()
+        s = {p: rm.get_pass(p) for p in ("beauty", "normal", "tangent", "bitangent")}
+        s["rng"], s["samples"], s["counters"] = rm.read_rng(), rm.read_samples(), rm.counters()
+        rm.close()
+        assert si["waves"] == int(waves)
+        print(f"waves {waves} ext {ext} counters {count}: speculative samples started {si['spec_started']}, right {si['spec_right']}, wrong {si['spec_wrong']}")
+        assert si["spec_right"] > 1000 and si["spec_wrong"] > 1000 and si["spec_started"] >= si["spec_right"] + si["spec_wrong"]
+        for p in ("beauty", "normal", "tangent", "bitangent"):
+            assert (w[p].view(np.uint32) == s[p].view(np.uint32)).all(), p
+        assert (w["rng"] == s["rng"]).all() and (w["samples"] == s["samples"]).all()
+        keys = ["paths", "bounce_samples", "rays", "shaded_hits", "hdri_samples"] + (["node_visits", "tri_tests", "texel_fetches"] if count else [])
+        for k in keys:
+            assert w["counters"][k] == s["counters"][k], (k, w["counters"][k], s["counters"][k])
