@@ -10,7 +10,12 @@
 // exactly once and its result was there when its slot was shaded; every ring ended empty with every cell in the state its lap
 // implies; no guard expired.
 //
-//   ring_model <slots> <pixels> <samples> <variant> [tracers] [shaders] [rq_log2]
+//   ring_model <slots> <pixels> <samples> <variant> [tracers] [shaders] [rq_log2] [spec]
+//     spec 1     with the speculative samples of round 6 (er_stream.hip ST_DRAWS_MASK): a pixel's next sample starts in a FREE slot (a fourth
+//                checked ring) from a guessed stream state and is accumulated only after its predecessor and only if the predecessor left that
+//                state -- the verdict word (exchange by the committing slot, compare-and-swap by a speculative slot that parks), the wake
+//                through the finish ring and the dropped samples' slots falling free are the hand-offs; checked at the end: every pixel's
+//                samples accumulated once, in order, each from the TRUE state (the pixel's stream state equals the sum of its samples' draws)
 //     variant 0  the protocol of the kernel
 //     variant 2  the same, but producers do NOT wait for the previous lap's reader (the protocol of round 2: plain overwrite) --
 //                a negative control: with small rings this loses rays or reads the wrong lap, and the model says so
@@ -51,10 +56,19 @@ struct Slot {              // plain memory: one slot record (HBM on the device)
     uint32_t pushed[3] = {0, 0, 0};     // ray identities the shader pushed for this step (0 = none)
     bool fin_next = false;
     uint32_t light = 0;                 // written by the shading step that ends the path, read by the finishing step (plain: the finish ring orders them)
+    // speculative samples (plain unless said otherwise: the protocol orders them)
+    std::atomic<uint32_t> spec_word{0}; // SP_* of a speculative slot: exchanged by the committing slot, compare-and-swapped by the slot itself
+    uint32_t spec_link = 0;             // local slot + 1 of the speculative sample this slot's sample started
+    uint64_t start_state = 0;           // the stream state this sample started from (a speculative one: the guess)
+    uint32_t spec_entry = 0;            // the finish-ring payload a parked speculative slot arrived with
+    bool is_spec = false;
 };
+enum { SP_NONE = 0, SP_PENDING = 1, SP_PARKED = 2, SP_VALID = 3, SP_INVALID = 4 };
 struct Pixel {
-    uint32_t done = 0;                  // plain: only the holder touches it
-    std::atomic<int> holders{0};
+    uint32_t done = 0;                  // plain: only the slot that accumulates touches it
+    std::atomic<int> holders{0};        // slots running a NON-speculative sample of the pixel (never two)
+    uint64_t state = 0;                 // the pixel's stream state = draws of all its accumulated samples (plain)
+    uint32_t guess = 0, conf = 0;       // DevScene::px_draws
 };
 
 struct Ring {
@@ -69,7 +83,9 @@ struct Model {
     std::vector<Slot> slots;
     std::vector<Pixel> pixels;
     std::vector<uint32_t> s_wait;
-    Ring rq, sq, fq, px;   // px: only ctl is used as a ring; its cells are px_cells + px_bits
+    Ring rq, sq, fq, px, fr;   // px: only ctl is used as a ring; its cells are px_cells + px_bits; fr: free slots (speculative samples)
+    bool spec = false;
+    std::atomic<uint32_t> spec_started{0}, spec_right{0}, spec_wrong{0};
     std::vector<uint64_t> px_cells;
     std::vector<uint32_t> px_bits;
     uint32_t px_cap = 0;
@@ -89,6 +105,7 @@ struct Model {
         if (cells == rq.cells.data()) { log2 = rq.log2; return "ray ring"; }
         if (cells == sq.cells.data()) { log2 = sq.log2; return "shade ring"; }
         if (cells == fq.cells.data()) { log2 = fq.log2; return "finish ring"; }
+        if (cells == fr.cells.data()) { log2 = fr.log2; return "free ring"; }
         if (cells == px_bits.data()) return "pixel ring bits";
         if (cells == px_cells.data()) return "pixel ring cell";
         return "?";
@@ -104,7 +121,7 @@ struct Model {
             fprintf(stderr, "  %-11s cap %4u  TAIL %u  COUNT %u  HEAD %u  (reserved and not yet granted: %u)\n", n, 1u << r.log2, er_ring_load(&r.ctl[ER_RING_TAIL]),
                     er_ring_load(&r.ctl[ER_RING_COUNT]), er_ring_load(&r.ctl[ER_RING_HEAD]), er_ring_load(&r.ctl[ER_RING_TAIL]) - er_ring_load(&r.ctl[ER_RING_HEAD]));
         };
-        d("ray ring", rq); d("shade ring", sq); d("finish ring", fq);
+        d("ray ring", rq); d("shade ring", sq); d("finish ring", fq); d("free ring", fr);
         fprintf(stderr, "  %-11s cap %4u  TAIL %u  COUNT %u  HEAD %u\n", "pixel ring", px_cap, er_ring_load(&px.ctl[ER_RING_TAIL]), er_ring_load(&px.ctl[ER_RING_COUNT]), er_ring_load(&px.ctl[ER_RING_HEAD]));
         fprintf(stderr, "  live slots %u, done %u\n", er_ring_load(&live), er_ring_load(&done));
         const auto now = std::chrono::steady_clock::now();
@@ -133,6 +150,8 @@ struct Model {
     // does the path's last closest-hit ray leave the scene (else it ends at the bounce limit)?  is a shadow query's verdict ambiguous?
     bool escapes(uint32_t pixel, uint32_t sample) const { return (hash32(pixel * 419u + sample * 61u + 3u) & 3u) != 0; }
     bool ambiguous(uint32_t ident) const { return (hash32(ident ^ 0x5bd1e995u) & 7u) == 0; }
+    // random numbers a sample draws: mostly the pixel's own figure, now and then another (so that guesses are right often and wrong sometimes)
+    uint32_t draws(uint32_t pixel, uint32_t sample) const { return 5u + 5u * ((hash32(pixel * 0x9e37u + 11u) + ((hash32(pixel * 131u + sample * 977u) & 3u) == 0u ? 1u : 0u)) % 3u); }
 
     // wave-level push of up to LANES payloads (one reservation)
     void push(Ring& r, const uint32_t* payload, int n, bool checked = true) {
@@ -156,10 +175,13 @@ struct Model {
         return (int)g;
     }
 
-    void begin_sample(uint32_t s, uint32_t pixel, uint32_t left) {
+    void begin_sample(uint32_t s, uint32_t pixel, uint32_t left, bool speculative = false, uint32_t sample = 0, uint64_t guessed_state = 0) {
         Slot& S = slots[s];
-        if (pixels[pixel].holders.fetch_add(1) != 0) err("a pixel is held by two slots");
-        S.pixel = pixel; S.left = left; S.sample = pixels[pixel].done; S.bounce = 0; S.fin_next = false;
+        if (!speculative && pixels[pixel].holders.fetch_add(1) != 0) err("a pixel is held by two slots");
+        S.pixel = pixel; S.left = left; S.sample = speculative ? sample : pixels[pixel].done; S.bounce = 0; S.fin_next = false;
+        S.is_spec = speculative; S.spec_link = 0; S.spec_entry = 0;
+        S.start_state = speculative ? guessed_state : pixels[pixel].state;
+        S.spec_word.store(speculative ? SP_PENDING : SP_NONE, std::memory_order_relaxed);
         S.pushed[0] = 1u + hash32(pixel * 31u + S.sample * 7u);      // the camera ray
         S.pushed[1] = S.pushed[2] = 0;
         S.result[0] = S.result[1] = S.result[2] = 0;
@@ -232,18 +254,41 @@ struct Model {
                 continue;
             }
             idle = 0;
-            uint32_t rays[3 * LANES];
+            uint32_t rays[4 * LANES];
             int n_rays = 0;
             uint32_t want_px[LANES], back_px[LANES], back_left[LANES];
             int n_want = 0, n_back = 0;
             uint32_t fin[LANES];
             int n_fin = 0;
+            uint32_t wake[LANES], frees[2 * LANES], spawned[LANES];
+            int n_wake = 0, n_free = 0, n_spawned = 0;
+            uint32_t dropped = 0;
             for (int i = 0; i < g && fin_mode; i++) {
                 // FINISHING step: the sample is accumulated, the pixel goes back, the slot takes the next one
                 const uint32_t s = e[i] & ((1u << SLOT_BITS) - 1u);
                 const bool from_tracer = (e[i] >> SLOT_BITS) != 0;
                 if (s >= n_slots) { err("garbage finish-ring entry"); continue; }
                 Slot& S = slots[s];
+                if (spec && S.is_spec) {
+                    // a speculative sample reaches its finishing step: verdict there -> accumulate or drop; not yet -> park (er_stream.hip)
+                    uint32_t sw = S.spec_word.load(std::memory_order_acquire);
+                    if (sw == SP_PENDING) {
+                        S.spec_entry = e[i];
+                        uint32_t expect = SP_PENDING;
+                        if (S.spec_word.compare_exchange_strong(expect, SP_PARKED, std::memory_order_acq_rel)) continue;      // the committing slot wakes it
+                        sw = expect;
+                    }
+                    if (sw == SP_INVALID) {      // dropped: nothing of it is accumulated, the slot falls free
+                        for (int k = 0; k < 3; k++) { S.pushed[k] = 0; S.result[k] = 0; }
+                        S.light = 0; S.is_spec = false;
+                        frees[n_free++] = s; dropped++;
+                        continue;
+                    }
+                    if (sw != SP_VALID) { err("a speculative slot in an impossible state"); continue; }
+                    S.is_spec = false;
+                    S.spec_word.store(SP_NONE, std::memory_order_relaxed);
+                    if (pixels[S.pixel].holders.fetch_add(1) != 0) err("a pixel is held by two slots");      // it is the pixel's sample in flight now
+                }
                 if (from_tracer) {
                     shortcuts.fetch_add(1);
                     // straight from the tracers: the last ray escaped and no verdict is ambiguous -- what the shading step checks and does
@@ -262,9 +307,27 @@ struct Model {
                 }
                 Pixel& P = pixels[S.pixel];
                 if (P.done != S.sample) err("a pixel's samples ran out of order");
+                if (S.start_state != P.state) err("a sample was accumulated from a wrong guess of the stream state");
+                const uint32_t nd = draws(S.pixel, S.sample);
+                P.state += nd;
+                if (nd == P.guess) P.conf = P.conf < 7u ? P.conf + 1u : 7u;
+                else if (P.conf >= 2u) P.conf -= 2u;
+                else { P.guess = nd; P.conf = 1u; }
                 P.done++;
                 P.holders.fetch_sub(1);
-                if (S.left - 1 > 0) { back_px[n_back] = S.pixel; back_left[n_back] = S.left - 1; n_back++; }
+                bool has_spec = false;
+                if (spec && S.spec_link) {
+                    // the verdict for the speculative sample this one started: right iff this sample left exactly the state it assumed
+                    Slot& F = slots[S.spec_link - 1u];
+                    const bool ok = F.start_state == P.state;
+                    const uint32_t old = F.spec_word.exchange(ok ? SP_VALID : SP_INVALID, std::memory_order_acq_rel);
+                    (ok ? spec_right : spec_wrong).fetch_add(1);
+                    if (old == SP_PARKED) wake[n_wake++] = F.spec_entry;
+                    else if (old != SP_PENDING) err("a verdict written twice");
+                    has_spec = ok;
+                    S.spec_link = 0;
+                }
+                if (S.left - 1 > 0 && !has_spec) { back_px[n_back] = S.pixel; back_left[n_back] = S.left - 1; n_back++; }
                 want_px[n_want++] = s;
             }
             for (int i = 0; i < g && !fin_mode; i++) {
@@ -277,6 +340,11 @@ struct Model {
                     if (S.pushed[k] && S.result[k] != 1u + hash32(S.pushed[k])) err("a slot was shaded before its ray was traced");
                     if (!S.pushed[k] && S.result[k]) err("a result without a ray");
                     S.pushed[k] = 0; S.result[k] = 0;
+                }
+                if (spec && S.is_spec && S.spec_word.load(std::memory_order_acquire) == SP_INVALID) {      // dropped at its next step
+                    S.light = 0; S.is_spec = false; S.fin_next = false;
+                    frees[n_free++] = s; dropped++;
+                    continue;
                 }
                 bool donep = fin_only;
                 bool pend_shadow = false, pend_light = false;
@@ -336,8 +404,27 @@ struct Model {
                     if (pixel >= n_pixels || left == 0) { err("garbage pixel-ring entry"); retire++; continue; }
                     begin_sample(want_px[i], pixel, left);
                     rays[n_rays++] = want_px[i];
+                    if (spec && left > 1u && pixels[pixel].conf >= 2u) {
+                        // the pixel's next sample at once, in a free slot, from the state this one leaves if it draws what the pixel's samples have been drawing
+                        uint32_t f = 0;
+                        if (take(fr, 1u, &f) == 1) {
+                            Slot& H = slots[want_px[i]];
+                            begin_sample(f, pixel, left - 1u, true, H.sample + 1u, H.start_state + pixels[pixel].guess);
+                            H.spec_link = f + 1u;
+                            er_ring_add(&live, 1u);
+                            spec_started.fetch_add(1);
+                            spawned[n_spawned++] = f;
+                        }
+                    }
                 }
+                for (int i = 0; i < n_want; i++) if ((uint32_t)i >= got && spec) frees[n_free++] = want_px[i];      // no pixel left for the slot: it is free
             }
+            for (int i = 0; i < n_spawned; i++) rays[n_rays++] = spawned[i];
+            push(fq, wake, n_wake, variant != 2);
+            // slots without a sample fall free: the dropped speculative ones (which also leave the count of samples in flight) and those that found no pixel
+            push(fr, frees, n_free > LANES ? LANES : n_free, variant != 2);
+            if (n_free > LANES) push(fr, frees + LANES, n_free - LANES, variant != 2);
+            retire += dropped;
             // publish the rays (one reservation per LANES entries, as st_push)
             rays_pushed.fetch_add((uint32_t)n_rays);
             for (int o = 0; o < n_rays; o += LANES) push(rq, rays + o, n_rays - o < LANES ? n_rays - o : LANES, variant != 2);
@@ -349,12 +436,12 @@ struct Model {
     }
 
     int run(uint32_t tracers, uint32_t shaders, uint32_t rq_log2) {
-        slots.assign(n_slots, Slot());
+        slots = std::vector<Slot>(n_slots);
         pixels = std::vector<Pixel>(n_pixels);
         s_wait.assign(n_slots, 0u);
         uint32_t sq_log2 = 0;
         while ((1u << sq_log2) < n_slots) sq_log2++;
-        rq.init(rq_log2); sq.init(sq_log2); fq.init(sq_log2);
+        rq.init(rq_log2); sq.init(sq_log2); fq.init(sq_log2); fr.init(sq_log2);
         px_cap = 1;
         while (px_cap < n_pixels) px_cap <<= 1;
         px_cells.assign(px_cap, 0);
@@ -371,6 +458,11 @@ struct Model {
         done = in_slots == 0 ? 1u : 0u;
         std::vector<uint32_t> first;
         for (uint32_t s = 0; s < in_slots; s++) { begin_sample(s, s, n_samples); first.push_back(s); }
+        if (spec) {      // the slots no pixel started in are free from the beginning
+            std::vector<uint32_t> idle;
+            for (uint32_t s = in_slots; s < n_slots; s++) idle.push_back(s);
+            for (size_t o = 0; o < idle.size(); o += LANES) push(fr, idle.data() + o, (int)(idle.size() - o < (size_t)LANES ? idle.size() - o : LANES));
+        }
         rays_pushed.fetch_add(in_slots);
         std::vector<std::thread> th;
         reg("main (camera rays)", 0);
@@ -393,7 +485,12 @@ struct Model {
         stop.store(true);
         monitor.join();
         uint32_t short_px = 0;
-        for (uint32_t p = 0; p < n_pixels; p++) if (pixels[p].done != n_samples) short_px++;
+        for (uint32_t p = 0; p < n_pixels; p++) {
+            if (pixels[p].done != n_samples) short_px++;
+            uint64_t want = 0;      // every sample accumulated once, from the true state: the stream state is the sum of the samples' draws
+            for (uint32_t k = 0; k < n_samples; k++) want += draws(p, k);
+            if (pixels[p].state != want) { short_px++; if (errors.fetch_add(1) < 10) fprintf(stderr, "model error: pixel %u ends in stream state %llu, not %llu\n", p, (unsigned long long)pixels[p].state, (unsigned long long)want); }
+        }
         auto ring_clean = [&](Ring& r, const char* name, uint32_t expect) {
             if (r.ctl[ER_RING_COUNT] != expect || r.ctl[ER_RING_TAIL] - r.ctl[ER_RING_HEAD] != expect) { fprintf(stderr, "%s: count %u, tail - head %u, expected %u\n", name, r.ctl[ER_RING_COUNT], r.ctl[ER_RING_TAIL] - r.ctl[ER_RING_HEAD], expect); return 1u; }
             // every cell in the state its next position implies: the first position >= HEAD that maps to the cell is either
@@ -415,6 +512,13 @@ struct Model {
             for (uint32_t w : px_bits) if (w) bad++;
         }
         if (px.ctl[ER_RING_COUNT] != 0) bad++;
+        if (spec && variant != 2) {      // at the end every slot is free, once
+            bad += ring_clean(fr, "free ring", n_slots);
+            std::vector<uint32_t> seen(n_slots, 0u);
+            for (uint32_t i = 0; i < (1u << fr.log2); i++) if (fr.cells[i] & ER_RING_FULL) { const uint32_t v = fr.cells[i] & ER_RING_PAYLOAD_MASK; if (v < n_slots) seen[v]++; }
+            for (uint32_t v : seen) if (v != 1u) bad++;
+            printf("speculative samples: %u started, %u guesses right, %u wrong\n", spec_started.load(), spec_right.load(), spec_wrong.load());
+        }
         const uint32_t lost = rays_pushed.load() - rays_traced.load();
         printf("variant %u slots %u pixels %u samples %u: %u pixels short, %u rays pushed, %u lost, %u protocol errors, %u ring faults, laps: ray ring %u, pixel ring %u, short cuts %u\n",
                variant, in_slots, n_pixels, n_samples, short_px, rays_pushed.load(), lost, errors.load(), bad, rq.ctl[ER_RING_TAIL] >> rq.log2,
@@ -475,6 +579,7 @@ int main(int argc, char** argv) {
     m.variant = argc > 4 ? (uint32_t)atoi(argv[4]) : 0;
     const uint32_t tracers = argc > 5 ? (uint32_t)atoi(argv[5]) : 3, shaders = argc > 6 ? (uint32_t)atoi(argv[6]) : 2;
     const uint32_t rq_log2 = argc > 7 ? (uint32_t)atoi(argv[7]) : 3;
+    m.spec = argc > 8 && atoi(argv[8]) != 0;
     if (m.n_slots > (1u << SLOT_BITS) || m.n_slots == 0 || m.n_pixels == 0 || (m.variant != 0 && m.variant != 2 && m.variant != 3)) return 2;
     // Start-up preconditions (the kernel's are static_asserts in er_stream.hip):
     //  * a wave's reservation must fit the ray ring -- else its later puts wait for readers of its own unpublished entries: a cycle.

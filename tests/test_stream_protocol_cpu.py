@@ -69,10 +69,33 @@ def test_every_ray_once_every_sample_in_order_every_ring_empty(model, cfg):
         assert int(r.stdout.split("short cuts ")[1]) > 0, r.stdout       # escaped paths did go from the tracers straight to the finish ring
 
 
+# slots, pixels, samples, tracer waves, shader waves, log2(ray ring cells): more slots than pixels, so that slots are free for speculative samples
+SPEC_CONFIGS = [(16, 6, 300, 3, 3, 4), (24, 10, 200, 4, 3, 4), (12, 5, 400, 3, 3, 3), (8, 24, 200, 3, 2, 3)]
+
+
+@pytest.mark.parametrize("cfg", SPEC_CONFIGS, ids=lambda c: "x".join(str(v) for v in c))
+def test_speculative_samples_every_sample_once_in_order_from_the_true_state(model, cfg):
+    """Round 6: the speculative samples of the small-share forms of the kernel (csrc/er_stream.hip ST_DRAWS_MASK) in the model: a pixel's next
+    sample starts in a free slot (a fourth checked ring) from a GUESSED stream state, and is accumulated only after its predecessor and
+    only if the predecessor left that state; the verdict word is exchanged by the committing slot and compare-and-swapped by a speculative
+    slot that parks, a parked slot comes back through the finish ring, a dropped one falls free.  The model checks at every accumulation
+    that the sample started from the pixel's TRUE state and at the end that every pixel's state is the sum of its samples' draws (each
+    accumulated once, in order), that every slot ended free exactly once and every ring empty; guesses must have been right AND wrong."""
+    slots, pixels, samples, tracers, shaders, rq_log2 = cfg
+    r = _run(model, slots, pixels, samples, 0, tracers, shaders, rq_log2, 1)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    assert "0 pixels short" in r.stdout and " 0 lost, 0 protocol errors, 0 ring faults" in r.stdout
+    started, right, wrong = (int(x) for x in r.stdout.split("speculative samples: ")[1].replace(" started, ", " ").replace(" guesses right, ", " ").replace(" wrong", "").split()[:3])
+    assert started >= right + wrong
+    if slots > pixels:
+        assert right > 20 and wrong > 5, r.stdout
+
+
 def test_thread_sanitizer_finds_no_unordered_hand_off(model_tsan):
-    for cfg in [(8, 24, 60, 3, 2, 3), (6, 40, 30, 4, 3, 2), (4, 4, 300, 3, 3, 2), (16, 16, 100, 6, 4, 4)]:
-        slots, pixels, samples, tracers, shaders, rq_log2 = cfg
-        r = _run(model_tsan, slots, pixels, samples, 0, tracers, shaders, rq_log2, timeout=600)
+    for cfg in [(8, 24, 60, 3, 2, 3, 0), (6, 40, 30, 4, 3, 2, 0), (4, 4, 300, 3, 3, 2, 0), (16, 16, 100, 6, 4, 4, 0),
+                (16, 6, 80, 3, 3, 4, 1), (24, 10, 60, 4, 3, 4, 1), (12, 5, 100, 3, 3, 3, 1)]:      # (the last three: with speculative samples)
+        slots, pixels, samples, tracers, shaders, rq_log2, spec = cfg
+        r = _run(model_tsan, slots, pixels, samples, 0, tracers, shaders, rq_log2, spec, timeout=600)
         assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
         assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
 
