@@ -1153,6 +1153,7 @@ hipError_t er_probe_stream(const char** which) {
     hipFuncAttributes a;
     *which = "er_stream_kernel";
     hipError_t e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 1024u, false, false>);
+    if (e == hipSuccess) e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 768u, true, false>);
     return e != hipSuccess ? e : hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 768u, true, true>);
 }
 
@@ -1251,7 +1252,8 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
     // (FUSE: an instance without the fused-texel path for scenes in which no material is fused, er_device.h generate_hit_data)
     const bool fuse = S.fused_any != 0u;
     auto pick = [&](auto with, auto without) { return fuse ? with : without; };
-    // instances: counters x extensions x fused textures, in three forms: 16 waves (whole frames), 16 waves with speculative samples, 12 waves with them
+    // instances: counters x extensions x fused textures, in four forms: 16 and 12 waves, each with and without speculative samples (the forms without
+    // are the code of round 5: whole frames, and the shares and scenes that start no speculative samples)
 #define ST_PICK(THREADS, SPECV)                                                                                                                                  \
     (count ? (ext ? pick(er_stream_kernel<true, true, THREADS, true, SPECV>, er_stream_kernel<true, true, THREADS, false, SPECV>)                                 \
                   : pick(er_stream_kernel<true, false, THREADS, true, SPECV>, er_stream_kernel<true, false, THREADS, false, SPECV>))                               \
@@ -1259,7 +1261,8 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
                   : pick(er_stream_kernel<false, false, THREADS, true, SPECV>, er_stream_kernel<false, false, THREADS, false, SPECV>)))
     auto k16 = ST_PICK(1024u, false);
     auto k16s = ST_PICK(1024u, true);
-    auto k12 = ST_PICK(768u, true);
+    auto k12s = ST_PICK(768u, true);
+    auto k12 = ST_PICK(768u, false);
 #undef ST_PICK
     StState st;
     st.base = (char*)records;
@@ -1267,7 +1270,8 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
     st.slots = slots;
     st.stride = er_stream_record_bytes(lights);
     const DevScene __attribute__((address_space(4)))* dS = (const DevScene __attribute__((address_space(4)))*)S_dev;
-    if (waves == 12u) hipLaunchKernelGGL(k12, dim3(blocks), dim3(768), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min | spec_now);
+    if (waves == 12u && spec && spec_now) hipLaunchKernelGGL(k12s, dim3(blocks), dim3(768), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min | spec_now);
+    else if (waves == 12u) hipLaunchKernelGGL(k12, dim3(blocks), dim3(768), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
     else if (spec && spec_now) hipLaunchKernelGGL(k16s, dim3(blocks), dim3(1024), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min | spec_now);
     else hipLaunchKernelGGL(k16, dim3(blocks), dim3(1024), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
 }
