@@ -458,9 +458,13 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         // 3 shader waves of 168 registers (the shading step then spills 34 registers instead of 111 and three shader waves serve what four
         // did): 1.23 vs 1.35 ms per pass at 1/8 (1 012 pixels per CU); at 1/6 (1 350 pixels) 16 waves are ahead again, 1.43 vs 1.47 (profiles/r04_sweep_small_shares.log)
         s->stream_waves = 16;
+        uint32_t small_tracers = 9;
         {
             const size_t px_per_cu = owned.size() * 64 / std::max<uint32_t>(1u, s->stream_blocks);
-            if (px_per_cu <= ER_STREAM_SMALL_SHARE) { s->stream_waves = 12; s->stream_tracers = 9; }
+            // (round 6, profiles/r06_ab_long_pixels_and_split.log: with the shading step as short as it has become two shader waves serve ten tracers where
+            // the slots are nearly all taken -- 1/8 ... 1/11 of the C2 frame 4.5 ... 1.5 % faster, C5's 1/8 share 1 ... 3 % -- and from 1/12 down 9 + 3 is ahead by 2 %)
+            small_tracers = px_per_cu > ER_STREAM_TEN_TRACERS_SHARE ? 10u : 9u;
+            if (px_per_cu <= ER_STREAM_SMALL_SHARE) { s->stream_waves = 12; s->stream_tracers = small_tracers; }
             // the lane occupancy says something about the balance of the two roles only where pixels are plentiful: a share of a few
             // pixels per slot cannot fill the lanes whatever the split (an eighth of a 1080p frame: 0.59 at the fastest split)
             // (nor in the instrumented kernel of ER_FLAG_COUNTERS, whose slower tracer loop shifts the balance)
@@ -468,7 +472,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             s->stream_spec_form = px_per_cu <= ER_STREAM_SPEC_SHARE;      // few pixels per slot: slots fall free, speculative samples can use them (er_stream.hip)
         }
         if (const char* e = getenv("ER_STREAM_SPEC_FORM")) s->stream_spec_form = atoi(e) != 0;      // A/B knob
-        if (const char* e = getenv("ER_STREAM_WAVES")) { s->stream_waves = atoi(e) == 12 ? 12 : 16; s->stream_tracers = s->stream_waves == 12 ? 9u : ((lights_on || s->tri_count > 4000000u) ? 12u : 13u); }   // A/B knob
+        if (const char* e = getenv("ER_STREAM_WAVES")) { s->stream_waves = atoi(e) == 12 ? 12 : 16; s->stream_tracers = s->stream_waves == 12 ? small_tracers : ((lights_on || s->tri_count > 4000000u) ? 12u : 13u); }   // A/B knob
         if (const char* e = getenv("ER_STREAM_TRACERS")) { s->stream_tracers = (uint32_t)std::min(13, std::max(1, atoi(e))); s->stream_adapt = false; }   // tuning knob: fixed split
         if (const char* e = getenv("ER_STREAM_ADAPT")) s->stream_adapt = atoi(e) != 0;
         s->stream_tracers_start = s->stream_tracers; s->stream_low_streak = 0; s->stream_up_budget = 1; s->stream_readings = 0;
@@ -518,7 +522,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             }
         }
         if ((rc = upload(s->d_px_draws, nullptr, npx, s->stream)) != ER_OK) return rc;
-        HIP_TRY(hipMemsetAsync(s->d_px_draws.p, 0, npx * sizeof(uint16_t), s->stream));
+        HIP_TRY(hipMemsetAsync(s->d_px_draws.p, 0, npx * sizeof(uint32_t), s->stream));
         if ((rc = upload(s->d_deal, deal.data(), deal.size(), s->stream)) != ER_OK) return rc;
         HIP_TRY(hipStreamSynchronize(s->stream));          // (`deal` goes out of scope)
         if (s->x_res > 65535u || s->y_res > 65535u)

@@ -102,7 +102,7 @@ struct DevScene {
     // have (bits 0-6: how many random numbers a sample draws; 0 = none yet) and a saturating confidence in it (bits 8-10: + 1 for every
     // accumulated sample that drew that many, - 2 for every other one; at 0 the latest count becomes the guess).  A guess, never a
     // result: not part of the progressive state (er_state_export), zeroed by er_render_begin
-    uint16_t* px_draws;
+    uint32_t* px_draws;
 };
 
 // Where pass `pass` of pixel `idx` lives in DevScene::passes.  The four planes a finished sample is accumulated into -- beauty, normal,

@@ -198,7 +198,7 @@ struct ErScene {
     bool stream_spec_form = false;                      //   launch the kernel's form with speculative samples (small shares)
     bool stream_probe_launch = false;                   //   the launch just completed was the first sample of a render's first call, run alone to decide the deal (er_render_samples)
     bool stream_deal_pending = false;                   //   the first completed call decides between the two (er_stream_adapt), from ...
-    DevBuf<uint16_t> d_px_draws;                         //   ... DevScene::px_draws
+    DevBuf<uint32_t> d_px_draws;                         //   ... DevScene::px_draws
     DevBuf<uint32_t> d_tile_cost;                       //   ... DevScene::tile_cost: per tile of the frame, the summed path lengths of its finished samples
     std::vector<uint32_t> stream_deal_large;            //   host copy of the large deal until then (which XCD gets which tile under it)
     double stream_cost_spread = -1.0;                   //   (max - min) / mean of the XCDs' counted work under the large deal; < 0: not decided yet

@@ -34,11 +34,17 @@ struct WfState;
 #ifndef ER_STREAM_SMALL_SHARE
 #define ER_STREAM_SMALL_SHARE 1152u  // owned pixels per CU up to which a workgroup runs as 12 waves of 168 registers (9 tracers + 3 shaders) instead of 16 of 128
 #endif
+#ifndef ER_STREAM_TEN_TRACERS_SHARE
+#define ER_STREAM_TEN_TRACERS_SHARE 704u   // ... of which 10 trace above this many owned pixels per CU, 9 up to it
+#endif
 #ifndef ER_STREAM_SPEC_SHARE
 #define ER_STREAM_SPEC_SHARE 2304u   // owned pixels per CU up to which the kernel's form with speculative samples is launched (`spec`; the 12-wave form always is)
 #endif
 #ifndef ER_STREAM_SPEC_MIN_TRIS
 #define ER_STREAM_SPEC_MIN_TRIS 1000u   // scenes of fewer triangles never start speculative samples (er_stream.hip ST_DRAWS_MASK; C1: -9 % with them)
+#endif
+#ifndef ER_STREAM_SPEC_LONG_DEFAULT
+#define ER_STREAM_SPEC_LONG_DEFAULT 12  // sixteenths of max_bounces: pixels whose paths are longer than that on average start a speculative successor with every sample
 #endif
 #define ER_STREAM_MAX_RING 32768u  // cells of a workgroup's pixel ring at most (one "entry read" bit per cell in LDS): a rank may own
                                   // up to 256 x 32768 = 8.4 M pixels under this schedule (a 4K frame), beyond that er_render_begin takes the wavefront one

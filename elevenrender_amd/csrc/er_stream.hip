@@ -293,6 +293,9 @@ struct StState {
 // is what a small share's launch lasts.
 #define ST_DRAWS_MASK 0x7Fu          // DevScene::px_draws: the guessed draw count of the pixel's samples | confidence in it << ST_CONF_SHIFT (0 .. 7)
 #define ST_CONF_SHIFT 8
+#define ST_VOTE_SHIFT 11             // ... | votes (0 .. 7) for ...
+#define ST_MAJ_SHIFT 16              // ... the draw count most of its samples had | ...
+#define ST_LONG_SHIFT 23             // ... the mean length of its paths, iterations x 16 (0 .. 511)
 enum { SP_NONE = 0, SP_PENDING = 1, SP_PARKED = 2, SP_VALID = 3, SP_INVALID = 4 };      // StState::spec_word of a speculative slot
 
 // pixel k of workgroup b's share: entry b + (k / 64) * workgroups of the deal (er_stream_deal_tiles below), lane k % 64
@@ -373,7 +376,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     bool spec_on = false;
     uint32_t spec_need = 0;      // the confidence (1 .. 7) a pixel's guess needs for a speculative start; 0 = no speculation
     uint32_t spec_slack = 0;     // ... and the polls a shader wave must have waited for work before a step in which it may start speculative samples
-    if (SPEC) { spec_need = (fin_min >> 8) & 7u; spec_slack = fin_min >> 12; spec_on = spec_need != 0u && S.px_draws != nullptr; fin_min &= 0xFFu; }
+    uint32_t spec_long = 0;      // ... and the mean path length (iterations x 16) from which a pixel's samples ALWAYS start a speculative successor (0 = never)
+    if (SPEC) { spec_need = (fin_min >> 8) & 7u; spec_slack = (fin_min >> 12) & 0xFFu; spec_long = (fin_min >> 20) & 0x1FFu; spec_on = spec_need != 0u && S.px_draws != nullptr; fin_min &= 0xFFu; }
     __shared__ uint32_t s_free[SPEC ? (1u << ST_SQ_LOG2) : 1u];      // ring of free slots (SPEC): slots whose pixel ring ran dry, and the slots beyond the share's pixels
     __shared__ __attribute__((aligned(8))) uint32_t s_free_ctl[ER_RING_WORDS];
     __shared__ uint32_t s_rq[1u << RQ_LOG2];
@@ -939,11 +943,20 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                         nd = nd > ST_DRAWS_MASK ? 0u : nd;      // (longer than the field: no guess for this pixel)
                         // a saturating counter per pixel, as a branch predictor keeps one per branch: the guess stays while it is mostly right
                         const uint32_t oldh = S.px_draws[idx];
-                        uint32_t cand = oldh & ST_DRAWS_MASK, conf = oldh >> ST_CONF_SHIFT;
+                        uint32_t cand = oldh & ST_DRAWS_MASK, conf = (oldh >> ST_CONF_SHIFT) & 7u;
                         if (nd != 0u && nd == cand) conf = conf < 7u ? conf + 1u : 7u;
                         else if (conf >= 2u) conf -= 2u;
                         else { cand = nd; conf = nd != 0u ? 1u : 0u; }
-                        S.px_draws[idx] = (uint16_t)(cand | (conf << ST_CONF_SHIFT));
+                        // ... and for the pixels a small share's launch ends on -- those whose paths are long, ST_LONG_SHIFT -- the count MOST of its
+                        // samples drew (a majority vote: + 1 / - 1, replaced at zero) and the mean length of its paths (iterations x 16, an
+                        // exponential average over about eight samples)
+                        uint32_t maj = (oldh >> ST_MAJ_SHIFT) & ST_DRAWS_MASK, votes = (oldh >> ST_VOTE_SHIFT) & 7u, mean16 = oldh >> ST_LONG_SHIFT;
+                        if (nd != 0u && nd == maj) votes = votes < 7u ? votes + 1u : 7u;
+                        else if (votes > 0u) votes--;
+                        else { maj = nd; votes = nd != 0u ? 1u : 0u; }
+                        const uint32_t its16 = ((ta & 0x3FFu) + ((e >> ST_SLOT_BITS) != 0 ? 1u : 0u)) << 4;
+                        mean16 = (uint32_t)((int)mean16 + (((int)(its16 > 511u ? 511u : its16) - (int)mean16) >> 3));
+                        S.px_draws[idx] = cand | (conf << ST_CONF_SHIFT) | (votes << ST_VOTE_SHIFT) | (maj << ST_MAJ_SHIFT) | (mean16 << ST_LONG_SHIFT);
                     }
                     const uint32_t link = W.spec_link(slot);
                     if (link) {
@@ -1018,11 +1031,13 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                         spawn_rs = st_begin_sample<SPEC>(S, W, slot, nidx, y);
                         if (SPEC && spec_on && y > 1u) {
                             const uint32_t h = S.px_draws[st_pixel_index(S, nidx)];
-                            spawn_draws = h & ST_DRAWS_MASK;
+                            const bool longp = spec_long != 0u && (h >> ST_LONG_SHIFT) >= spec_long;
+                            const bool sure = ((h >> ST_CONF_SHIFT) & 7u) >= spec_need;
+                            spawn_draws = (longp && !sure) ? ((h >> ST_MAJ_SHIFT) & ST_DRAWS_MASK) : (h & ST_DRAWS_MASK);
                             // (... and only from a shader wave that has been WAITING for work: where the shader waves never wait another sample in
                             // flight adds to their queue, not to the pixel's progress -- C1's 12-triangle box is bound by its three shader waves and
                             // ran 9 % slower with every pixel two samples deep)
-                            spawn_want = spawn_draws != 0u && (h >> ST_CONF_SHIFT) >= spec_need && waited >= spec_slack;
+                            spawn_want = spawn_draws != 0u && (longp || sure) && waited >= spec_slack;
                         }
                         spawn_pxy = nidx; spawn_left = y - 1u;
                         s_wait[ls] = 1u;
@@ -1238,12 +1253,20 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
         const char* e = getenv("ER_STREAM_SPEC");
         const char* b = getenv("ER_STREAM_SPEC_SLACK");      // polls a shader wave must have waited before a step that starts speculative samples (knob; 0 = no condition)
         int v = e ? atoi(e) : 2, bl = b ? atoi(b) : 1;
-        return ((uint32_t)(v < 0 ? 0 : (v > 7 ? 7 : v)) << 8) | ((uint32_t)(bl < 0 ? 0 : (bl > 4096 ? 4096 : bl)) << 12);
+        return ((uint32_t)(v < 0 ? 0 : (v > 7 ? 7 : v)) << 8) | ((uint32_t)(bl < 0 ? 0 : (bl > 255 ? 255 : bl)) << 12);
+    }();
+    // ER_STREAM_SPEC_LONG: sixteenths of max_bounces; a pixel whose paths are longer than that on average starts a speculative successor with every sample (0 = off)
+    static const uint32_t spec_long16 = [] {
+        const char* e = getenv("ER_STREAM_SPEC_LONG");
+        int v = e ? atoi(e) : ER_STREAM_SPEC_LONG_DEFAULT;
+        return (uint32_t)(v < 0 ? 0 : (v > 16 ? 16 : v));
     }();
     if (S.owned_tile_count == 0 || n_samples == 0) return;
     // (a slot's tally keeps its iterations in ten bits; and a scene of a few triangles -- C1's 12-triangle box, 256 pixels per CU -- runs 5-9 % SLOWER two
     // samples deep, right guesses and all: its rays are three traversal steps long and there is nothing to overlap, profiles/r06_ab_speculative_samples.log)
-    const uint32_t spec_now = (S.max_bounces <= 1000u && S.tri_count >= ER_STREAM_SPEC_MIN_TRIS) ? spec_flag : 0u;
+    // (iterations x 16; the field holds up to 511: longer paths, no such pixels.  12-wave form only: 1/16 share of the C2 frame - 5 %, 1/8 - 0 ... 2 %; the 16-wave form's 1/4 share + 0.6 %)
+    const uint32_t long_thr = waves == 12u ? S.max_bounces * spec_long16 : 0u;
+    const uint32_t spec_now = (S.max_bounces <= 1000u && S.tri_count >= ER_STREAM_SPEC_MIN_TRIS) ? (spec_flag | ((long_thr > 511u ? 0u : long_thr) << 20)) : 0u;
     if (tracers > ST_MAX_TRACERS) tracers = ST_MAX_TRACERS;      // (the LDS traversal stacks are sized for that many; at least 3 shader waves stay)
     waves = waves == 12u ? 12u : 16u;
     if (tracers > waves - 1u) tracers = waves - 1u;      // at least one shader wave
