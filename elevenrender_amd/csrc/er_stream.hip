@@ -387,6 +387,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     __shared__ uint32_t s_pxbits[ST_PXBITS_WORDS];
     __shared__ __attribute__((aligned(8))) uint32_t s_rq_ctl[ER_RING_WORDS], s_sq_ctl[ER_RING_WORDS], s_px_ctl[ER_RING_WORDS], s_fq_ctl[ER_RING_WORDS];
     __shared__ uint32_t s_ctl[C_WORDS];
+    __shared__ uint32_t s_spec[SPEC ? 3 : 1];       // (SPEC) speculative samples started / guesses right / wrong: counted in LDS (no registers), every wave flushes what it finds when it leaves
     __shared__ float4 s_top[TOP_NODES * 5];          // (the LDS copy stays compact -- five pieces per node -- whatever the stride in device memory)
 #ifdef ER_TIME_PROBE
     __shared__ uint32_t s_tp[13];      // [1..9] cycles / 16 per section of the shader loop, [10] shader steps, [11] slots shaded, [12] cycles / 16 of tracer iterations
@@ -407,6 +408,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     if (SPEC) for (uint32_t i = threadIdx.x; i < (1u << ST_SQ_LOG2); i += ST_THREADS) s_free[i] = 0;
     if (threadIdx.x < ER_RING_WORDS) { s_rq_ctl[threadIdx.x] = 0; s_sq_ctl[threadIdx.x] = 0; s_px_ctl[threadIdx.x] = 0; s_fq_ctl[threadIdx.x] = 0; }
     if (SPEC && threadIdx.x < ER_RING_WORDS) s_free_ctl[threadIdx.x] = 0;
+    if (SPEC && threadIdx.x < 3u) s_spec[threadIdx.x] = 0;
     if (threadIdx.x < C_WORDS) s_ctl[threadIdx.x] = 0;
     __syncthreads();
     // this workgroup's pixels in the order of its tiles: the first SLOTS valid ones start in the slots, the others
@@ -458,7 +460,6 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     unsigned c_rays = 0, c_nodes = 0, c_tris = 0;
     unsigned c_paths = 0, c_bounce = 0, c_shaded = 0, c_texels = 0, c_hdri = 0;
     unsigned c_wsteps = 0, c_busy = 0, c_nl = 0, c_tl = 0;
-    unsigned c_spec[3] = {0, 0, 0};      // (SPEC) speculative samples started / guesses right / wrong
 
     {
         __shared__ uint2 s_stack[ST_MAX_TRACERS * WF_LDS_STACK * 64];
@@ -763,12 +764,20 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
             // A speculative sample whose guess was wrong is dropped where it stands -- at its next shading step or at its finishing step -- and its
             // slot falls free: the pixel's sample has been started over, from the true state, by the slot that wrote the verdict (so a wrong
             // guess costs the work of a path, never time in the chain of the pixel's samples)
+            // (the verdict word is requested here, with the step's other loads, and looked at when the step is over: a dropped sample's step runs like any
+            // other and is thrown away whole)
+            uint32_t cancel_w = (uint32_t)SP_NONE;
+            if (SPEC && spec_on && have && !fin_mode) cancel_w = __hip_atomic_load(&W.spec_word(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (SPEC && discard) retire = true;
             bool cancel = false;
-            if (SPEC && spec_on && have && !fin_mode) cancel = __hip_atomic_load(&W.spec_word(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == (uint32_t)SP_INVALID;
-            if (SPEC && (discard || cancel)) retire = true;
-            // (SPEC) what this step counts goes to the slot's tally, not to the lane's accumulators: it is counted when the sample is accumulated
-            const unsigned k_b0 = c_bounce, k_sh0 = c_shaded, k_hd0 = c_hdri, k_tx0 = c_texels, k_nd0 = c_nodes, k_tr0 = c_tris;
-            if (have && !fin_mode && !cancel) {
+            // (SPEC) what this step counts goes to the slot's tally, not to the lane's accumulators -- it is counted when the sample is accumulated: inside
+            // the step the counters' names mean step-local ones (no value to save and put back across the step, no read of the tally: one atomic add at its end)
+            unsigned &o_bounce = c_bounce, &o_shaded = c_shaded, &o_hdri = c_hdri, &o_texels = c_texels, &o_nodes = c_nodes, &o_tris = c_tris;
+            if (have && !fin_mode) {
+                unsigned t_bounce = 0, t_shaded = 0, t_hdri = 0, t_texels = 0, t_nodes = 0, t_tris = 0;
+                unsigned &c_bounce = SPEC ? t_bounce : o_bounce, &c_shaded = SPEC ? t_shaded : o_shaded, &c_hdri = SPEC ? t_hdri : o_hdri;
+                unsigned &c_texels = SPEC ? t_texels : o_texels, &c_nodes = SPEC ? t_nodes : o_nodes, &c_tris = SPEC ? t_tris : o_tris;
+                (void)c_texels;
                 const bool fin_only = (e >> ST_SLOT_BITS) != 0;
                 float4 L4 = W.light(slot), R4 = W.reduc(slot);
                 F3 light = f3(L4.x, L4.y, L4.z), reduction = f3(R4.x, R4.y, R4.z);
@@ -861,16 +870,23 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                                                 __builtin_bit_cast(float, bounce | (pending ? WF_PENDING_BIT : 0u) | ((EXT && lpending) ? WF_LPENDING_BIT : 0u)));
                     s_wait[ls] = (push_closest ? 1u : 0u) + (push_shadow ? 1u : 0u) + (push_light ? 1u : 0u) + (fin_next ? ST_FIN : 0u);
                 }
-            }
-            if (SPEC && have && !fin_mode && !cancel) {
-                W.tally_a(slot) += (c_bounce - k_b0) | ((c_shaded - k_sh0) << 10) | ((c_hdri - k_hd0) << 20);
-                W.tally_rays(slot) += (push_closest ? 1u : 0u) + (push_shadow ? 1u : 0u) + (push_light ? 1u : 0u);
-                if (COUNT) {
-                    W.tally_tex(slot) += c_texels - k_tx0;
-                    atomicAdd(&W.tally_nodes(slot), c_nodes - k_nd0);      // (the tracers add to these two as well)
-                    atomicAdd(&W.tally_tris(slot), c_tris - k_tr0);
+                if (SPEC) {
+                    cancel = cancel_w == (uint32_t)SP_INVALID;
+                    if (!cancel) {
+                        // (tally_a | tally_rays << 32 in one add; the fields of the low word never carry into the high one: <= 1 000 iterations)
+                        const unsigned long long add = (unsigned long long)(t_bounce | (t_shaded << 10) | (t_hdri << 20)) |
+                                                       ((unsigned long long)((push_closest ? 1u : 0u) + (push_shadow ? 1u : 0u) + (push_light ? 1u : 0u)) << 32);
+                        __hip_atomic_fetch_add((unsigned long long*)&W.tally_a(slot), add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (COUNT) {
+                            W.tally_tex(slot) += t_texels;
+                            atomicAdd(&W.tally_nodes(slot), t_nodes);      // (the tracers add to these two as well)
+                            atomicAdd(&W.tally_tris(slot), t_tris);
+                        }
+                    } else {
+                        push_closest = false; push_shadow = false; push_light = false; to_finish = false;
+                        retire = true;
+                    }
                 }
-                c_bounce = k_b0; c_shaded = k_sh0; c_hdri = k_hd0; c_texels = k_tx0; c_nodes = k_nd0; c_tris = k_tr0;
             }
             if (!fin_mode) {
                 if (__ballot(to_finish)) {
@@ -965,7 +981,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                         const bool ok = W.spec_start(f) == rs;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the planes and the RNG state first, then the verdict
                         const uint32_t old = atomicExch(&W.spec_word(f), ok ? (uint32_t)SP_VALID : (uint32_t)SP_INVALID);
-                        c_spec[ok ? 1 : 2]++;      // (statistics: guesses right / wrong)
+                        atomicAdd(&s_spec[ok ? 1 : 2], 1u);      // (statistics: guesses right / wrong)
                         if (old == (uint32_t)SP_PARKED) {      // it has finished its path and waits: this lane puts it back on the finish ring
                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                             wake = true;
@@ -1075,8 +1091,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                     const unsigned long long mgot = __ballot(got_free);
                     if (mgot && lane == (int)(__ffsll((long long)mgot) - 1)) {
                         atomicAdd(&s_ctl[C_LIVE], (uint32_t)__popcll(mgot));      // before any slot of this step retires
+                        atomicAdd(&s_spec[0], (uint32_t)__popcll(mgot));          // (statistics: speculative samples started)
                     }
-                    if (got_free) c_spec[0]++;      // (statistics: speculative samples started; flushed once per wave at the end)
                 }
             }
             if (SPEC && spec_on && __ballot(wake)) {
@@ -1139,8 +1155,10 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     return;
 #endif
     if (SPEC) {
-        const unsigned q0 = st_wave_sum(c_spec[0]), q1 = st_wave_sum(c_spec[1]), q2 = st_wave_sum(c_spec[2]);
-        if (lane == 0 && (q0 | q1 | q2)) { atomicAdd(status + 23, q0); atomicAdd(status + 24, q1); atomicAdd(status + 25, q2); }
+        if (lane == 0) {
+            const unsigned q0 = atomicExch(&s_spec[0], 0u), q1 = atomicExch(&s_spec[1], 0u), q2 = atomicExch(&s_spec[2], 0u);
+            if (q0 | q1 | q2) { atomicAdd(status + 23, q0); atomicAdd(status + 24, q1); atomicAdd(status + 25, q2); }
+        }
     }
     unsigned t0 = st_wave_sum(c_paths), t1 = st_wave_sum(c_bounce), t2 = st_wave_sum(c_rays), t3 = st_wave_sum(c_shaded), t4 = st_wave_sum(c_hdri);
     unsigned t5 = 0, t6 = 0, t7 = 0;
