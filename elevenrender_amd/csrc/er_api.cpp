@@ -231,7 +231,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         er_build_bvh(s->vertices.data(), s->normals.data(), s->tri_count, 0, &bvh);
         HIP_TRY(hipEventRecord(u0, s->stream));
         if (bvh.max_depth > ER_BVH_MAX_DEPTH) return fail(ER_ERR_STATE, "er_render_begin: BVH deeper than the traversal stack");
-        if (bvh.max_depth8 > ER_BVH_MAX_DEPTH) return fail(ER_ERR_STATE, "er_render_begin: wide BVH deeper than the traversal stack");
+        if (bvh.max_depth8 > ER_STACK8) return fail(ER_ERR_STATE, "er_render_begin: wide BVH deeper than the traversal stack (ER_STACK8)");
         isect.resize(n + 1);      // +1: the wide traversal fetches triangles in pairs
         attr.resize(n);
         for (size_t slot = 0; slot < n; slot++) {
@@ -575,7 +575,7 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
         if (const char* e = getenv("ER_TRACE_WAVES_PER_CU")) s->trace_blocks = cus * (uint32_t)std::max(1, atoi(e));   // tuning knob
         if (const char* e = getenv("ER_SHADE_WAVES_PER_CU")) s->shade_blocks = cus * (uint32_t)std::max(1, atoi(e));
         // (uint2 entries: the trace waves' stack levels beyond the LDS ones, then the shade waves' exact re-trace stacks, two ints per entry)
-        const size_t trace_spill = (size_t)s->trace_blocks * ER_BVH_MAX_DEPTH * 64;
+        const size_t trace_spill = (size_t)s->trace_blocks * ER_STACK8 * 64;
         const size_t spill_per_pool = trace_spill + (size_t)s->shade_blocks * ER_BVH_MAX_DEPTH * 32;
         if ((rc = upload(s->d_spill, nullptr, spill_per_pool * pools, s->stream)) != ER_OK) return rc;
         s->wf.clear();

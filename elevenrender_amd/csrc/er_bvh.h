@@ -16,6 +16,16 @@
 #include <vector>
 
 #define ER_BVH_MAX_DEPTH 64   // also the stack depth per lane of the binary-tree routines (32 until round 5: the device builder's trees of 10 M triangles are deeper)
+// Stack levels of the WIDE traversal (one entry per level of the 8-wide tree at most): the first WF_LDS_STACK (er_trav.h) of them in LDS, the others in the HBM spill
+// area, which is sized for all of them.  The wide tree is far shallower than the binary one it is collapsed from (C2: 9 levels, C4: 11; the binary
+// routines' own stacks stay ER_BVH_MAX_DEPTH deep, ER_STACK in er_device.h); er_render_begin refuses a scene whose wide tree is deeper.
+#ifndef ER_STACK8
+#define ER_STACK8 32
+#endif
+// uint2 entries of ONE wave's spill region where a wave may play either role (streaming schedule, debug hooks): the wide traversal's levels or the
+// exact binary re-trace's int stack (ER_BVH_MAX_DEPTH levels x 64 lanes, two ints per entry)
+#define ER_SPILL_PER_WAVE ((ER_STACK8 * 64) > (ER_BVH_MAX_DEPTH * 32) ? (ER_STACK8 * 64) : (ER_BVH_MAX_DEPTH * 32))
+
 #ifndef ER_BVH_LEAF_MAX
 #define ER_BVH_LEAF_MAX 2   // measured on C2: 2 -> 838, 3 -> 792, 4 -> 764 Msamples/s (fewer triangle fetches per ray)
 #endif

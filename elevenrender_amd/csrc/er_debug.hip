@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64) void er_debug_trace_kernel(DevScene S, const fl
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
     if (i >= n) return;
     uint2* stack = s_stack + threadIdx.x;
-    uint2* spill = spill_base + (size_t)blockIdx.x * (ER_STACK * 64) + threadIdx.x;
+    uint2* spill = spill_base + (size_t)blockIdx.x * (ER_STACK8 * 64) + threadIdx.x;
     int* stack2 = s_stack2 + threadIdx.x;
     Ray ray;
     ray.o = f3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
@@ -62,8 +62,8 @@ __global__ __launch_bounds__(64) void er_debug_pixel_kernel(DevScene S, uint32_t
     // addresses them as LDS -- the deeper levels and the exact re-trace's stack in the HBM scratch buffer)
     __shared__ uint2 sh_stack[WF_LDS_STACK * 64];
     uint2* s_stack = sh_stack;
-    int* s_stack2 = (int*)(spill + (size_t)ER_STACK * 64);
-    static_assert((size_t)ER_STACK * 64 + ((size_t)ER_STACK * 64 * sizeof(int) + sizeof(uint2) - 1) / sizeof(uint2) <= (size_t)ER_DEBUG_PIXEL_SCRATCH,
+    int* s_stack2 = (int*)(spill + (size_t)ER_STACK8 * 64);
+    static_assert((size_t)ER_STACK8 * 64 + ((size_t)ER_STACK * 64 * sizeof(int) + sizeof(uint2) - 1) / sizeof(uint2) <= (size_t)ER_DEBUG_PIXEL_SCRATCH,
                   "er_debug_trace_pixel's scratch must hold the spill levels and the exact routine's int stack");
     if (threadIdx.x != 0) return;
     int nrec = 0;

@@ -150,7 +150,7 @@ static int er_debug_trace_rays_impl(ErScene* s, const float* origins, const floa
     if ((rc = upload(d_tri, (const int32_t*)nullptr, (size_t)n, s->stream)) != ER_OK) return rc;
     if ((rc = upload(d_slot, (const int32_t*)nullptr, (size_t)n, s->stream)) != ER_OK) return rc;
     if ((rc = upload(d_info, (const int32_t*)nullptr, (size_t)n, s->stream)) != ER_OK) return rc;
-    if ((rc = upload(d_spill, (const uint2*)nullptr, (size_t)((n + 63) / 64) * ER_BVH_MAX_DEPTH * 64, s->stream)) != ER_OK) return rc;
+    if ((rc = upload(d_spill, (const uint2*)nullptr, (size_t)((n + 63) / 64) * ER_STACK8 * 64, s->stream)) != ER_OK) return rc;
     er_launch_debug_trace(s->dev, d_o.p, d_d.p, n, self_slots ? d_self.p : nullptr, self_slots ? d_lim.p : nullptr, d_tri.p, d_slot.p, d_pos.p,
                           d_dist.p, d_info.p, d_spill.p, s->stream);
     HIP_TRY(hipGetLastError());

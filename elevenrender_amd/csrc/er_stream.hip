@@ -467,7 +467,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
         // from here on the waves run their own loops: NO workgroup barrier below this line
         if (wave < tracers) {
             // =========================== tracer: er_wf_trace's loop, fed from the ray ring ===========================
-            uint2* spill = W.spill + (size_t)(blockIdx.x * 16u + wave) * (ER_STACK * 64) + lane;
+            uint2* spill = W.spill + (size_t)(blockIdx.x * 16u + wave) * ER_SPILL_PER_WAVE + lane;
             uint2* stack = s_stack + (size_t)wave * (WF_LDS_STACK * 64) + lane;
             Trav T;
             trav_begin(T, f3s(0), f3(0, 0, 1), false, -1, 0.0f);
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     if (wave >= tracers) {
         // =========================== shader: er_wf_shade's step, fed from the shade ring ===========================
         // exact re-trace (rare): its stack in HBM (the tracer waves use the first `tracers` areas of the workgroup, the shader waves the others)
-        int* stack = (int*)(W.spill + (size_t)(blockIdx.x * 16u + wave) * (ER_STACK * 64)) + lane;
+        int* stack = (int*)(W.spill + (size_t)(blockIdx.x * 16u + wave) * ER_SPILL_PER_WAVE) + lane;
         bool have = false;
         uint32_t e = 0;
         uint32_t idle = 0, spins = 0, progress = 0;
@@ -1318,6 +1318,6 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
 }
 
 uint32_t er_stream_record_bytes(bool lights) { return lights ? ST_STRIDE_LIGHTS : ST_STRIDE_PLAIN; }
-// uint2 entries of the spill buffer: per workgroup 16 waves x (ER_BVH_MAX_DEPTH x 64): a tracer wave's stack levels beyond the LDS ones,
-// a shader wave's exact re-trace stack (ints, two per entry)
-size_t er_stream_spill_entries(uint32_t blocks) { return (size_t)blocks * 16 * ER_BVH_MAX_DEPTH * 64; }
+// uint2 entries of the spill buffer: per workgroup 16 waves x ER_SPILL_PER_WAVE (er_trav.h): a tracer wave's stack levels beyond the LDS ones
+// (ER_STACK8 levels of the wide tree), a shader wave's exact re-trace stack (ER_STACK ints per lane, two per entry): 16 KB per wave, 67 MB on 256 CUs
+size_t er_stream_spill_entries(uint32_t blocks) { return (size_t)blocks * 16 * ER_SPILL_PER_WAVE; }

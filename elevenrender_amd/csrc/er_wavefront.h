@@ -40,7 +40,7 @@ struct WfState {
     uint32_t* q[2];    // closest queues (slot | flags), ping-pong by iteration parity
     uint32_t* qs[2];   // shadow queues (slot)
     uint32_t* counts;  // WF_COUNTS words
-    uint2* spill;      // per persistent trace wave: ER_BVH_MAX_DEPTH x 64 stack entries beyond the LDS levels
+    uint2* spill;      // per persistent trace wave: ER_STACK8 x 64 stack entries beyond the LDS levels (er_trav.h)
     int* shade_stack;  // per shade wave: ER_BVH_MAX_DEPTH x 64 ints, the stack of the rare exact re-trace (in LDS until round 5: 16 KB per wave at depth 64)
     uint32_t slots;    // owned_tile_count * 64.  With ER_FLAG_POINT_LIGHTS the shadow records (sh_o, sh_d, c_vis, c_occ,
                        // occluded, occ_a, occ_b) have 2 * slots entries: [slot] = the HDRI query, [slot + slots] = the

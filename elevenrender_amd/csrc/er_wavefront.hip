@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64, WF_TRACE_WAVES) void er_wf_trace(DevScene S, Wf
     __shared__ uint2 s_stack[WF_LDS_STACK * 64];
     const int lane = threadIdx.x;
     uint2* stack = s_stack + lane;
-    uint2* spill = W.spill + (size_t)blockIdx.x * (ER_STACK * 64) + lane;
+    uint2* spill = W.spill + (size_t)blockIdx.x * (ER_STACK8 * 64) + lane;
     const uint32_t nC = W.counts[WF_NC + WF_PAR(parity)], nS = W.counts[WF_NS + WF_PAR(parity)];
     if (blockIdx.x == 0 && lane == 0) {   // reset what the NEXT shade step appends to / pulls from
         W.counts[WF_NC + WF_PAR(parity ^ 1)] = 0;
