@@ -46,6 +46,9 @@ struct WfState;
 #ifndef ER_STREAM_SPEC_LONG_DEFAULT
 #define ER_STREAM_SPEC_LONG_DEFAULT 12  // sixteenths of max_bounces: pixels whose paths are longer than that on average start a speculative successor with every sample
 #endif
+#ifndef ER_STREAM_SPEC_KEEP_DEFAULT
+#define ER_STREAM_SPEC_KEEP_DEFAULT 2   // 1 + the samples a pixel may be behind its workgroup's most advanced one before it goes on in the slot it has (0 = off)
+#endif
 #define ER_STREAM_MAX_RING 32768u  // cells of a workgroup's pixel ring at most (one "entry read" bit per cell in LDS): a rank may own
                                   // up to 256 x 32768 = 8.4 M pixels under this schedule (a 4K frame), beyond that er_render_begin takes the wavefront one
 

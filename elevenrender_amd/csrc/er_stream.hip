@@ -377,7 +377,8 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     uint32_t spec_need = 0;      // the confidence (1 .. 7) a pixel's guess needs for a speculative start; 0 = no speculation
     uint32_t spec_slack = 0;     // ... and the polls a shader wave must have waited for work before a step in which it may start speculative samples
     uint32_t spec_long = 0;      // ... and the mean path length (iterations x 16) from which a pixel's samples ALWAYS start a speculative successor (0 = never)
-    if (SPEC) { spec_need = (fin_min >> 8) & 7u; spec_slack = (fin_min >> 12) & 0xFFu; spec_long = (fin_min >> 20) & 0x1FFu; spec_on = spec_need != 0u && S.px_draws != nullptr; fin_min &= 0xFFu; }
+    uint32_t spec_keep = 0;      // ... and 1 + the samples a pixel may be behind the workgroup's most advanced one before it goes on in the slot it has instead of queueing (0 = never)
+    if (SPEC) { spec_need = (fin_min >> 8) & 7u; spec_slack = (fin_min >> 12) & 0xFFu; spec_long = (fin_min >> 20) & 0x1FFu; spec_keep = fin_min >> 29; spec_on = spec_need != 0u && S.px_draws != nullptr; fin_min &= 0xFFu; }
     __shared__ uint32_t s_free[SPEC ? (1u << ST_SQ_LOG2) : 1u];      // ring of free slots (SPEC): slots whose pixel ring ran dry, and the slots beyond the share's pixels
     __shared__ __attribute__((aligned(8))) uint32_t s_free_ctl[ER_RING_WORDS];
     __shared__ uint32_t s_rq[1u << RQ_LOG2];
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     __shared__ uint32_t s_pxbits[ST_PXBITS_WORDS];
     __shared__ __attribute__((aligned(8))) uint32_t s_rq_ctl[ER_RING_WORDS], s_sq_ctl[ER_RING_WORDS], s_px_ctl[ER_RING_WORDS], s_fq_ctl[ER_RING_WORDS];
     __shared__ uint32_t s_ctl[C_WORDS];
+    __shared__ uint32_t s_front;         // (SPEC) the fewest samples any of the workgroup's pixels has left: the most advanced one
     __shared__ uint32_t s_spec[SPEC ? 3 : 1];       // (SPEC) speculative samples started / guesses right / wrong: counted in LDS (no registers), every wave flushes what it finds when it leaves
     __shared__ float4 s_top[TOP_NODES * 5];          // (the LDS copy stays compact -- five pieces per node -- whatever the stride in device memory)
 #ifdef ER_TIME_PROBE
@@ -409,6 +411,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     if (threadIdx.x < ER_RING_WORDS) { s_rq_ctl[threadIdx.x] = 0; s_sq_ctl[threadIdx.x] = 0; s_px_ctl[threadIdx.x] = 0; s_fq_ctl[threadIdx.x] = 0; }
     if (SPEC && threadIdx.x < ER_RING_WORDS) s_free_ctl[threadIdx.x] = 0;
     if (SPEC && threadIdx.x < 3u) s_spec[threadIdx.x] = 0;
+    if (SPEC && threadIdx.x == 0) s_front = 0xFFFFFFFFu;
     if (threadIdx.x < C_WORDS) s_ctl[threadIdx.x] = 0;
     __syncthreads();
     // this workgroup's pixels in the order of its tiles: the first SLOTS valid ones start in the slots, the others
@@ -736,7 +739,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
             uint32_t rs = 0, left_after = 0, done_idx = 0;
             // speculation (SPEC): this lane's sample continues in a speculative slot / wakes a parked speculative slot with this finish-ring entry /
             // has started a speculative sample in local slot ls_spec whose camera ray is to be queued
-            bool has_spec = false, wake = false, push_spec = false;
+            bool has_spec = false, wake = false, push_spec = false, keep_own = false;
             uint32_t wake_entry = 0, ls_spec = 0;
             ER_MARK("shader_step");
             ER_TPS(1);
@@ -996,12 +999,20 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 left_after = W.left(slot) - 1;
                 done_idx = pxy;
                 want_pixel = true;
+                // (the pixel ring is first in, first out: every pixel waits equally long for its next turn, so the cheap pixels of a share of a few pixels
+                // per slot take more turns per millisecond than the expensive ones, finish early, and leave the launch to the chains of the expensive
+                // ones.  A pixel that is BEHIND the workgroup's most advanced one goes on in the slot it has: all pixels then advance sample by sample
+                // together, and the expensive ones never wait)
+                if (SPEC && spec_keep != 0u) {
+                    const uint32_t front = atomicMin(&s_front, left_after);
+                    keep_own = left_after > 0u && !has_spec && left_after >= front + spec_keep;
+                }
             }
             ER_MARK("shader_pixel_ring");
             ER_TPS(7);
             // finished samples: pixel back to the tail of the pixel ring (unless that was its last sample), next pixel from the head
             if (__ballot(want_pixel)) {
-                const bool back = want_pixel && left_after > 0 && !has_spec;
+                const bool back = want_pixel && left_after > 0 && !has_spec && !(SPEC && keep_own);
                 const unsigned long long mb = __ballot(back);
                 if (mb) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the pixel's planes and RNG state first, then its entry
@@ -1020,11 +1031,12 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 // another slot has taken it)
                 bool spawn_want = false;
                 uint32_t spawn_rs = 0, spawn_pxy = 0, spawn_left = 0, spawn_draws = 0;
-                const unsigned long long mw = __ballot(want_pixel);
+                const bool want_take = want_pixel && !(SPEC && keep_own);
+                const unsigned long long mw = __ballot(want_take);
                 uint32_t hb2 = 0;
                 const uint32_t granted2 = st_take(s_px_ctl, (uint32_t)__popcll(mw), hb2, er_ring_peek(s_px_ctl));
                 const uint32_t rank = (uint32_t)__popcll(mw & below);
-                if (want_pixel && rank < granted2) {
+                if (want_take && rank < granted2) {
                     const uint32_t ppos = hb2 + rank, pcell = ppos & (ring_cap - 1u);
                     const unsigned long long* cell = (const unsigned long long*)(ring + pcell);
                     const uint32_t want_tag = ST_LAP_TAG(ppos, ring_cap);
@@ -1062,8 +1074,21 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                         atomicOr(status, ST_ERR_PIXEL);    // (cannot happen: a granted entry was never written)
                         retire = true;
                     }
-                } else if (want_pixel) {
+                } else if (want_take) {
                     retire = true;      // nothing left in the ring: the pixels still unfinished are all in flight in other slots
+                }
+                if (SPEC && keep_own) {
+                    spawn_rs = st_begin_sample<SPEC>(S, W, slot, done_idx, left_after);
+                    if (spec_on && left_after > 1u) {
+                        const uint32_t h = S.px_draws[st_pixel_index(S, done_idx)];
+                        const bool longp = spec_long != 0u && (h >> ST_LONG_SHIFT) >= spec_long;
+                        const bool sure = ((h >> ST_CONF_SHIFT) & 7u) >= spec_need;
+                        spawn_draws = (longp && !sure) ? ((h >> ST_MAJ_SHIFT) & ST_DRAWS_MASK) : (h & ST_DRAWS_MASK);
+                        spawn_want = spawn_draws != 0u && (longp || sure) && waited >= spec_slack;
+                    }
+                    spawn_pxy = done_idx; spawn_left = left_after - 1u;
+                    s_wait[ls] = 1u;
+                    push_closest = true;
                 }
                 if (SPEC && spec_on && __ballot(spawn_want)) {
                     // the samples just begun whose pixels' last samples drew equally many numbers: where a slot is free, the pixel's next sample starts
@@ -1279,12 +1304,18 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
         int v = e ? atoi(e) : ER_STREAM_SPEC_LONG_DEFAULT;
         return (uint32_t)(v < 0 ? 0 : (v > 16 ? 16 : v));
     }();
+    // ER_STREAM_SPEC_KEEP: 1 + the samples a pixel may be behind before it keeps its slot (0 = off, 1 .. 7)
+    static const uint32_t spec_keep = [] {
+        const char* e = getenv("ER_STREAM_SPEC_KEEP");
+        int v = e ? atoi(e) : ER_STREAM_SPEC_KEEP_DEFAULT;
+        return (uint32_t)(v < 0 ? 0 : (v > 7 ? 7 : v));
+    }();
     if (S.owned_tile_count == 0 || n_samples == 0) return;
     // (a slot's tally keeps its iterations in ten bits; and a scene of a few triangles -- C1's 12-triangle box, 256 pixels per CU -- runs 5-9 % SLOWER two
     // samples deep, right guesses and all: its rays are three traversal steps long and there is nothing to overlap, profiles/r06_ab_speculative_samples.log)
     // (iterations x 16; the field holds up to 511: longer paths, no such pixels.  12-wave form only: 1/16 share of the C2 frame - 5 %, 1/8 - 0 ... 2 %; the 16-wave form's 1/4 share + 0.6 %)
     const uint32_t long_thr = waves == 12u ? S.max_bounces * spec_long16 : 0u;
-    const uint32_t spec_now = (S.max_bounces <= 1000u && S.tri_count >= ER_STREAM_SPEC_MIN_TRIS) ? (spec_flag | ((long_thr > 511u ? 0u : long_thr) << 20)) : 0u;
+    const uint32_t spec_now = (S.max_bounces <= 1000u && S.tri_count >= ER_STREAM_SPEC_MIN_TRIS) ? (spec_flag | ((long_thr > 511u ? 0u : long_thr) << 20) | ((waves == 16u ? spec_keep : 0u) << 29)) : 0u;      // (the 16-wave form, whose pixels outnumber its slots: 1/4 share - 3.7 ... 5 %, 1/6 - 1 %; the 12-wave form's 1/8 ... 1/16 shares +- 0 ... + 1 %)
     if (tracers > ST_MAX_TRACERS) tracers = ST_MAX_TRACERS;      // (the LDS traversal stacks are sized for that many; at least 3 shader waves stay)
     waves = waves == 12u ? 12u : 16u;
     if (tracers > waves - 1u) tracers = waves - 1u;      // at least one shader wave
