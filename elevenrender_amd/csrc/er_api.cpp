@@ -469,9 +469,11 @@ static int er_render_begin_impl(ErScene* s, const ErRenderParams* p) {
             // pixels per slot cannot fill the lanes whatever the split (an eighth of a 1080p frame: 0.59 at the fastest split)
             // (nor in the instrumented kernel of ER_FLAG_COUNTERS, whose slower tracer loop shifts the balance)
             s->stream_adapt = px_per_cu >= 4u * ER_STREAM_SLOTS && !(p->flags & ER_FLAG_COUNTERS);
+            s->stream_keep = px_per_cu <= ER_STREAM_KEEP_SHARE;      // (er_stream.hip s_front)
             s->stream_spec_form = px_per_cu <= ER_STREAM_SPEC_SHARE;      // few pixels per slot: slots fall free, speculative samples can use them (er_stream.hip)
         }
         if (const char* e = getenv("ER_STREAM_SPEC_FORM")) s->stream_spec_form = atoi(e) != 0;      // A/B knob
+        if (const char* e = getenv("ER_STREAM_KEEP")) s->stream_keep = atoi(e) != 0;                // A/B knob
         if (const char* e = getenv("ER_STREAM_WAVES")) { s->stream_waves = atoi(e) == 12 ? 12 : 16; s->stream_tracers = s->stream_waves == 12 ? small_tracers : ((lights_on || s->tri_count > 4000000u) ? 12u : 13u); }   // A/B knob
         if (const char* e = getenv("ER_STREAM_TRACERS")) { s->stream_tracers = (uint32_t)std::min(13, std::max(1, atoi(e))); s->stream_adapt = false; }   // tuning knob: fixed split
         if (const char* e = getenv("ER_STREAM_ADAPT")) s->stream_adapt = atoi(e) != 0;
@@ -709,7 +711,7 @@ static int er_render_samples_async_impl(ErScene* s, uint32_t n) {
             HIP_TRY(hipMemsetAsync(s->stream_ctl + 6, 0xFF, 2 * sizeof(uint32_t), s->stream));    // ... and its start (a minimum)
             if (k > 0) s->stream_launches++;
             er_launch_stream(s->dev, s->d_dev.p, s->d_wf4.p, s->stream_blocks * ER_STREAM_SLOTS, s->stream_lights, s->d_spill.p, s->d_deal.p + s->stream_deal_off, s->stream_deal_n, s->d_ticket.p, s->stream_ring_cap, s->stream_ctl + 1, k, count,
-                             s->stream_blocks, s->stream_tracers, s->stream_waves, s->stream_spec_form, s->stream);
+                             s->stream_blocks, s->stream_tracers, s->stream_waves, s->stream_spec_form, s->stream_keep, s->stream);
             return ER_OK;
         };
         // Round 6: a render that is ONE call must get the deal its frame deserves too.  While the deal is undecided, the first call's

@@ -196,6 +196,7 @@ struct ErScene {
     uint32_t stream_deal_alt_off = 0, stream_deal_alt_n = 0;   //   the deal of large screen regions beside it (0 entries: none)
     uint64_t stream_spec[3] = {0, 0, 0}, stream_spec_seen = 0;   //   speculative samples started / whose guess was right / wrong, summed over the render's completed launches (small shares: er_stream.hip ST_PRED_BIT)
     bool stream_spec_form = false;                      //   launch the kernel's form with speculative samples (small shares)
+    bool stream_keep = false;                           //   a pixel that is behind its workgroup's most advanced one keeps its slot (er_stream.hip s_front)
     bool stream_probe_launch = false;                   //   the launch just completed was the first sample of a render's first call, run alone to decide the deal (er_render_samples)
     bool stream_deal_pending = false;                   //   the first completed call decides between the two (er_stream_adapt), from ...
     DevBuf<uint32_t> d_px_draws;                         //   ... DevScene::px_draws

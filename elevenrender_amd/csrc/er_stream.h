@@ -46,6 +46,11 @@ struct WfState;
 #ifndef ER_STREAM_SPEC_LONG_DEFAULT
 #define ER_STREAM_SPEC_LONG_DEFAULT 12  // sixteenths of max_bounces: pixels whose paths are longer than that on average start a speculative successor with every sample
 #endif
+#ifndef ER_STREAM_KEEP_SHARE
+#define ER_STREAM_KEEP_SHARE 6000u   // owned pixels per CU up to which the kernel's form is launched in which a pixel that is behind its workgroup's most advanced one keeps
+                                     // its slot (er_stream.hip s_front): C2's 1/2 and 1/3 shares 3 ... 5 % faster, a 200 000-triangle soup at 1280 x 720 (3 600 pixels per
+                                     // CU) 4.6 %; the whole C2 frame (8 100) +- 0.5 %: it stays in the plain form, the code of round 5
+#endif
 #ifndef ER_STREAM_SPEC_KEEP_DEFAULT
 #define ER_STREAM_SPEC_KEEP_DEFAULT 2   // 1 + the samples a pixel may be behind its workgroup's most advanced one before it goes on in the slot it has (0 = off)
 #endif
@@ -62,7 +67,7 @@ struct WfState;
 // a wave of XCD x = workgroup index % 8 (caller: zero), wall_clock64() ticks.
 // S_dev: a device copy of S (the kernel reads the scene descriptor from constant memory, not from its arguments).
 void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
-                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, bool spec, hipStream_t stream);
+                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, bool spec, bool keep, hipStream_t stream);
 // the deal of the owned tiles to the workgroups (device copy of `out` = `deal` above, deal_count = out.size()); returns the most tiles of one workgroup
 // edge: side of a super-tile in 8 x 8 tiles; 0 = ER_STREAM_SUPER_TILE from the environment, else ER_STREAM_SUPER_TILE_DEFAULT
 uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t tiles_x, uint32_t blocks, bool xcd_aware, std::vector<uint32_t>& out, uint32_t edge = 0);

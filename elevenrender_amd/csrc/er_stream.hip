@@ -360,7 +360,7 @@ __device__ __forceinline__ void st_write_result(const StState& W, uint32_t rec, 
 
 }  // namespace
 
-template <bool COUNT, bool EXT, uint32_t ST_THREADS, bool FUSE, bool SPECT>
+template <bool COUNT, bool EXT, uint32_t ST_THREADS, bool FUSE, int FORM>
 __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __attribute__((address_space(4)))* Sp, StState W, const uint32_t* deal, uint32_t deal_count, uint2* ring_base, uint32_t ring_cap,
                                                           uint32_t* status, uint32_t n_samples, uint32_t tracers, uint32_t refill_min, uint32_t batch_min, uint32_t fin_min) {
     // The scene descriptor lives in constant memory and is read with scalar loads where it is used.  As a by-value kernel argument its
@@ -370,15 +370,18 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     // the frame's COST over the XCDs is something only the run can tell (er_api.cpp er_stream_adapt)
     if (threadIdx.x == 0) atomicMin((unsigned long long*)(status + 5), (unsigned long long)wall_clock64());
     constexpr uint32_t RQ_LOG2 = ST_RQ_LOG2, SLOTS = ER_STREAM_SLOTS, TOP_NODES = ER_STREAM_TOP_NODES;
-    // speculative sample pipelining (comment at ST_DRAWS_MASK): a template argument -- the instances that render whole frames (SPECT = false: no slot
-    // ever falls free while pixels wait in the ring) are the code they were; er_launch_stream takes a SPECT instance for shares of few pixels per slot
-    constexpr bool SPEC = SPECT;
+    // The kernel's FORM is a template argument: 0 -- the instances that render whole frames, the code they were in round 5; 1 -- with the rule that
+    // a pixel which is behind keeps its slot (s_front), for shares of a few pixels per slot; 2 -- that and speculative sample pipelining (comment at
+    // ST_DRAWS_MASK), for shares in which slots fall free.  er_launch_stream picks by owned pixels per CU (er_api.cpp).
+    constexpr bool SPEC = FORM == 2;
+    constexpr bool KEEP = FORM >= 1;
     bool spec_on = false;
     uint32_t spec_need = 0;      // the confidence (1 .. 7) a pixel's guess needs for a speculative start; 0 = no speculation
     uint32_t spec_slack = 0;     // ... and the polls a shader wave must have waited for work before a step in which it may start speculative samples
     uint32_t spec_long = 0;      // ... and the mean path length (iterations x 16) from which a pixel's samples ALWAYS start a speculative successor (0 = never)
     uint32_t spec_keep = 0;      // ... and 1 + the samples a pixel may be behind the workgroup's most advanced one before it goes on in the slot it has instead of queueing (0 = never)
     if (SPEC) { spec_need = (fin_min >> 8) & 7u; spec_slack = (fin_min >> 12) & 0xFFu; spec_long = (fin_min >> 20) & 0x1FFu; spec_keep = fin_min >> 29; spec_on = spec_need != 0u && S.px_draws != nullptr; fin_min &= 0xFFu; }
+    else if (KEEP) { spec_keep = fin_min >> 29; fin_min &= 0xFFu; }
     __shared__ uint32_t s_free[SPEC ? (1u << ST_SQ_LOG2) : 1u];      // ring of free slots (SPEC): slots whose pixel ring ran dry, and the slots beyond the share's pixels
     __shared__ __attribute__((aligned(8))) uint32_t s_free_ctl[ER_RING_WORDS];
     __shared__ uint32_t s_rq[1u << RQ_LOG2];
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     __shared__ uint32_t s_pxbits[ST_PXBITS_WORDS];
     __shared__ __attribute__((aligned(8))) uint32_t s_rq_ctl[ER_RING_WORDS], s_sq_ctl[ER_RING_WORDS], s_px_ctl[ER_RING_WORDS], s_fq_ctl[ER_RING_WORDS];
     __shared__ uint32_t s_ctl[C_WORDS];
-    __shared__ uint32_t s_front;         // (SPEC) the fewest samples any of the workgroup's pixels has left: the most advanced one
+    __shared__ uint32_t s_front;         // the fewest samples any of the workgroup's pixels has left: the most advanced one
     __shared__ uint32_t s_spec[SPEC ? 3 : 1];       // (SPEC) speculative samples started / guesses right / wrong: counted in LDS (no registers), every wave flushes what it finds when it leaves
     __shared__ float4 s_top[TOP_NODES * 5];          // (the LDS copy stays compact -- five pieces per node -- whatever the stride in device memory)
 #ifdef ER_TIME_PROBE
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
     if (threadIdx.x < ER_RING_WORDS) { s_rq_ctl[threadIdx.x] = 0; s_sq_ctl[threadIdx.x] = 0; s_px_ctl[threadIdx.x] = 0; s_fq_ctl[threadIdx.x] = 0; }
     if (SPEC && threadIdx.x < ER_RING_WORDS) s_free_ctl[threadIdx.x] = 0;
     if (SPEC && threadIdx.x < 3u) s_spec[threadIdx.x] = 0;
-    if (SPEC && threadIdx.x == 0) s_front = 0xFFFFFFFFu;
+    if (KEEP && threadIdx.x == 0) s_front = 0xFFFFFFFFu;
     if (threadIdx.x < C_WORDS) s_ctl[threadIdx.x] = 0;
     __syncthreads();
     // this workgroup's pixels in the order of its tiles: the first SLOTS valid ones start in the slots, the others
@@ -1003,7 +1006,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 // per slot take more turns per millisecond than the expensive ones, finish early, and leave the launch to the chains of the expensive
                 // ones.  A pixel that is BEHIND the workgroup's most advanced one goes on in the slot it has: all pixels then advance sample by sample
                 // together, and the expensive ones never wait)
-                if (SPEC && spec_keep != 0u) {
+                if (KEEP && spec_keep != 0u) {
                     const uint32_t front = atomicMin(&s_front, left_after);
                     keep_own = left_after > 0u && !has_spec && left_after >= front + spec_keep;
                 }
@@ -1012,7 +1015,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
             ER_TPS(7);
             // finished samples: pixel back to the tail of the pixel ring (unless that was its last sample), next pixel from the head
             if (__ballot(want_pixel)) {
-                const bool back = want_pixel && left_after > 0 && !has_spec && !(SPEC && keep_own);
+                const bool back = want_pixel && left_after > 0 && !has_spec && !(KEEP && keep_own);
                 const unsigned long long mb = __ballot(back);
                 if (mb) {
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the pixel's planes and RNG state first, then its entry
@@ -1031,7 +1034,7 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 // another slot has taken it)
                 bool spawn_want = false;
                 uint32_t spawn_rs = 0, spawn_pxy = 0, spawn_left = 0, spawn_draws = 0;
-                const bool want_take = want_pixel && !(SPEC && keep_own);
+                const bool want_take = want_pixel && !(KEEP && keep_own);
                 const unsigned long long mw = __ballot(want_take);
                 uint32_t hb2 = 0;
                 const uint32_t granted2 = st_take(s_px_ctl, (uint32_t)__popcll(mw), hb2, er_ring_peek(s_px_ctl));
@@ -1077,9 +1080,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
                 } else if (want_take) {
                     retire = true;      // nothing left in the ring: the pixels still unfinished are all in flight in other slots
                 }
-                if (SPEC && keep_own) {
+                if (KEEP && keep_own) {
                     spawn_rs = st_begin_sample<SPEC>(S, W, slot, done_idx, left_after);
-                    if (spec_on && left_after > 1u) {
+                    if (SPEC && spec_on && left_after > 1u) {
                         const uint32_t h = S.px_draws[st_pixel_index(S, done_idx)];
                         const bool longp = spec_long != 0u && (h >> ST_LONG_SHIFT) >= spec_long;
                         const bool sure = ((h >> ST_CONF_SHIFT) & 7u) >= spec_need;
@@ -1210,9 +1213,9 @@ __global__ __launch_bounds__(ST_THREADS) void er_stream_kernel(const DevScene __
 hipError_t er_probe_stream(const char** which) {
     hipFuncAttributes a;
     *which = "er_stream_kernel";
-    hipError_t e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 1024u, false, false>);
-    if (e == hipSuccess) e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 768u, true, false>);
-    return e != hipSuccess ? e : hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 768u, true, true>);
+    hipError_t e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 1024u, false, 0>);
+    if (e == hipSuccess) e = hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 768u, true, 0>);
+    return e != hipSuccess ? e : hipFuncGetAttributes(&a, (const void*)er_stream_kernel<false, false, 768u, true, 2>);
 }
 
 // Which workgroup renders which tiles.  Workgroups b and b + 8 run on the same XCD and share its 4 MB L2 (observed dispatch
@@ -1270,7 +1273,7 @@ uint32_t er_stream_deal_tiles(const uint32_t* owned, uint32_t count, uint32_t ti
 }
 
 void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, uint32_t slots, bool lights, void* spill, const uint32_t* deal, uint32_t deal_count, void* ring,
-                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, bool spec, hipStream_t stream) {
+                      uint32_t ring_cap, uint32_t* status, uint32_t n_samples, bool count, uint32_t blocks, uint32_t tracers, uint32_t waves, bool spec, bool keep, hipStream_t stream) {
     static const uint32_t refill_min = [] {
         const char* e = getenv("ER_STREAM_REFILL_MIN");
         int v = e ? atoi(e) : 12;
@@ -1315,7 +1318,8 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
     // samples deep, right guesses and all: its rays are three traversal steps long and there is nothing to overlap, profiles/r06_ab_speculative_samples.log)
     // (iterations x 16; the field holds up to 511: longer paths, no such pixels.  12-wave form only: 1/16 share of the C2 frame - 5 %, 1/8 - 0 ... 2 %; the 16-wave form's 1/4 share + 0.6 %)
     const uint32_t long_thr = waves == 12u ? S.max_bounces * spec_long16 : 0u;
-    const uint32_t spec_now = (S.max_bounces <= 1000u && S.tri_count >= ER_STREAM_SPEC_MIN_TRIS) ? (spec_flag | ((long_thr > 511u ? 0u : long_thr) << 20) | ((waves == 16u ? spec_keep : 0u) << 29)) : 0u;      // (the 16-wave form, whose pixels outnumber its slots: 1/4 share - 3.7 ... 5 %, 1/6 - 1 %; the 12-wave form's 1/8 ... 1/16 shares +- 0 ... + 1 %)
+    const uint32_t spec_now = (S.max_bounces <= 1000u && S.tri_count >= ER_STREAM_SPEC_MIN_TRIS) ? (spec_flag | ((long_thr > 511u ? 0u : long_thr) << 20) | (((waves == 16u && keep) ? spec_keep : 0u) << 29)) : 0u;      // (the 16-wave form, whose pixels outnumber its slots: 1/4 share - 3.7 ... 5 %, 1/6 - 1 %; the 12-wave form's 1/8 ... 1/16 shares +- 0 ... + 1 %)
+    const uint32_t keep_plain = (keep && waves == 16u) ? (spec_keep << 29) : 0u;
     if (tracers > ST_MAX_TRACERS) tracers = ST_MAX_TRACERS;      // (the LDS traversal stacks are sized for that many; at least 3 shader waves stay)
     waves = waves == 12u ? 12u : 16u;
     if (tracers > waves - 1u) tracers = waves - 1u;      // at least one shader wave
@@ -1324,17 +1328,18 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
     // (FUSE: an instance without the fused-texel path for scenes in which no material is fused, er_device.h generate_hit_data)
     const bool fuse = S.fused_any != 0u;
     auto pick = [&](auto with, auto without) { return fuse ? with : without; };
-    // instances: counters x extensions x fused textures, in four forms: 16 and 12 waves, each with and without speculative samples (the forms without
-    // are the code of round 5: whole frames, and the shares and scenes that start no speculative samples)
+    // instances: counters x extensions x fused textures, in five forms: 16 waves plain / with the keep rule / with that and speculative samples,
+    // 12 waves plain / with speculative samples (the plain forms are the code of round 5: whole frames, and the scenes that start no speculative samples)
 #define ST_PICK(THREADS, SPECV)                                                                                                                                  \
     (count ? (ext ? pick(er_stream_kernel<true, true, THREADS, true, SPECV>, er_stream_kernel<true, true, THREADS, false, SPECV>)                                 \
                   : pick(er_stream_kernel<true, false, THREADS, true, SPECV>, er_stream_kernel<true, false, THREADS, false, SPECV>))                               \
            : (ext ? pick(er_stream_kernel<false, true, THREADS, true, SPECV>, er_stream_kernel<false, true, THREADS, false, SPECV>)                               \
                   : pick(er_stream_kernel<false, false, THREADS, true, SPECV>, er_stream_kernel<false, false, THREADS, false, SPECV>)))
-    auto k16 = ST_PICK(1024u, false);
-    auto k16s = ST_PICK(1024u, true);
-    auto k12s = ST_PICK(768u, true);
-    auto k12 = ST_PICK(768u, false);
+    auto k16 = ST_PICK(1024u, 0);
+    auto k16k = ST_PICK(1024u, 1);
+    auto k16s = ST_PICK(1024u, 2);
+    auto k12s = ST_PICK(768u, 2);
+    auto k12 = ST_PICK(768u, 0);
 #undef ST_PICK
     StState st;
     st.base = (char*)records;
@@ -1345,6 +1350,7 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
     if (waves == 12u && spec && spec_now) hipLaunchKernelGGL(k12s, dim3(blocks), dim3(768), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min | spec_now);
     else if (waves == 12u) hipLaunchKernelGGL(k12, dim3(blocks), dim3(768), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
     else if (spec && spec_now) hipLaunchKernelGGL(k16s, dim3(blocks), dim3(1024), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min | spec_now);
+    else if (keep_plain) hipLaunchKernelGGL(k16k, dim3(blocks), dim3(1024), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min | keep_plain);
     else hipLaunchKernelGGL(k16, dim3(blocks), dim3(1024), 0, stream, dS, st, deal, deal_count, (uint2*)ring, ring_cap, status, n_samples, tracers, refill_min, batch_min, fin_min);
 }
 
