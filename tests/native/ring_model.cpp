@@ -86,6 +86,8 @@ struct Model {
     Ring rq, sq, fq, px, fr;   // px: only ctl is used as a ring; its cells are px_cells + px_bits; fr: free slots (speculative samples)
     bool spec = false;
     std::atomic<uint32_t> spec_started{0}, spec_right{0}, spec_wrong{0};
+    uint32_t keep = 0;                  // 1 + the samples a pixel may be behind the most advanced one before it keeps its slot (0 = the rule is off)
+    std::atomic<uint32_t> front{0xFFFFFFFFu}, kept{0};
     std::vector<uint64_t> px_cells;
     std::vector<uint32_t> px_bits;
     uint32_t px_cap = 0;
@@ -263,6 +265,21 @@ struct Model {
             uint32_t wake[LANES], frees[2 * LANES], spawned[LANES];
             int n_wake = 0, n_free = 0, n_spawned = 0;
             uint32_t dropped = 0;
+            uint32_t kept_slot[LANES], kept_px[LANES], kept_left[LANES];
+            int n_kept = 0;
+            // the pixel's next sample at once, in a free slot, from the state the sample just begun in slot `h` leaves if it draws what the pixel's samples have been drawing
+            auto spawn = [&](uint32_t h, uint32_t pixel, uint32_t left) {
+                if (!(spec && left > 1u && pixels[pixel].conf >= 2u)) return;
+                uint32_t f = 0;
+                if (take(fr, 1u, &f) == 1) {
+                    Slot& H = slots[h];
+                    begin_sample(f, pixel, left - 1u, true, H.sample + 1u, H.start_state + pixels[pixel].guess);
+                    H.spec_link = f + 1u;
+                    er_ring_add(&live, 1u);
+                    spec_started.fetch_add(1);
+                    spawned[n_spawned++] = f;
+                }
+            };
             for (int i = 0; i < g && fin_mode; i++) {
                 // FINISHING step: the sample is accumulated, the pixel goes back, the slot takes the next one
                 const uint32_t s = e[i] & ((1u << SLOT_BITS) - 1u);
@@ -327,8 +344,19 @@ struct Model {
                     has_spec = ok;
                     S.spec_link = 0;
                 }
-                if (S.left - 1 > 0 && !has_spec) { back_px[n_back] = S.pixel; back_left[n_back] = S.left - 1; n_back++; }
-                want_px[n_want++] = s;
+                // a pixel that is `keep` - 1 or more samples behind the most advanced one goes on in the slot it has (er_stream.hip s_front)
+                bool keep_own = false;
+                if (keep) {
+                    const uint32_t la = S.left - 1;
+                    uint32_t fr0 = front.load(std::memory_order_relaxed);
+                    while (la < fr0 && !front.compare_exchange_weak(fr0, la, std::memory_order_relaxed)) {}
+                    keep_own = la > 0 && !has_spec && la >= fr0 + keep;
+                }
+                if (keep_own) { kept_slot[n_kept] = s; kept_px[n_kept] = S.pixel; kept_left[n_kept] = S.left - 1; n_kept++; kept.fetch_add(1); }
+                else {
+                    if (S.left - 1 > 0 && !has_spec) { back_px[n_back] = S.pixel; back_left[n_back] = S.left - 1; n_back++; }
+                    want_px[n_want++] = s;
+                }
             }
             for (int i = 0; i < g && !fin_mode; i++) {
                 const uint32_t s = e[i] & ((1u << SLOT_BITS) - 1u);
@@ -404,20 +432,14 @@ struct Model {
                     if (pixel >= n_pixels || left == 0) { err("garbage pixel-ring entry"); retire++; continue; }
                     begin_sample(want_px[i], pixel, left);
                     rays[n_rays++] = want_px[i];
-                    if (spec && left > 1u && pixels[pixel].conf >= 2u) {
-                        // the pixel's next sample at once, in a free slot, from the state this one leaves if it draws what the pixel's samples have been drawing
-                        uint32_t f = 0;
-                        if (take(fr, 1u, &f) == 1) {
-                            Slot& H = slots[want_px[i]];
-                            begin_sample(f, pixel, left - 1u, true, H.sample + 1u, H.start_state + pixels[pixel].guess);
-                            H.spec_link = f + 1u;
-                            er_ring_add(&live, 1u);
-                            spec_started.fetch_add(1);
-                            spawned[n_spawned++] = f;
-                        }
-                    }
+                    spawn(want_px[i], pixel, left);
                 }
                 for (int i = 0; i < n_want; i++) if ((uint32_t)i >= got && spec) frees[n_free++] = want_px[i];      // no pixel left for the slot: it is free
+            }
+            for (int i = 0; i < n_kept; i++) {      // the pixels that went on in their slots: no ring, the next sample from the state this one left
+                begin_sample(kept_slot[i], kept_px[i], kept_left[i]);
+                rays[n_rays++] = kept_slot[i];
+                spawn(kept_slot[i], kept_px[i], kept_left[i]);
             }
             for (int i = 0; i < n_spawned; i++) rays[n_rays++] = spawned[i];
             push(fq, wake, n_wake, variant != 2);
@@ -519,6 +541,7 @@ struct Model {
             for (uint32_t v : seen) if (v != 1u) bad++;
             printf("speculative samples: %u started, %u guesses right, %u wrong\n", spec_started.load(), spec_right.load(), spec_wrong.load());
         }
+        if (keep) printf("samples begun in the slot their pixel had: %u\n", kept.load());
         const uint32_t lost = rays_pushed.load() - rays_traced.load();
         printf("variant %u slots %u pixels %u samples %u: %u pixels short, %u rays pushed, %u lost, %u protocol errors, %u ring faults, laps: ray ring %u, pixel ring %u, short cuts %u\n",
                variant, in_slots, n_pixels, n_samples, short_px, rays_pushed.load(), lost, errors.load(), bad, rq.ctl[ER_RING_TAIL] >> rq.log2,
@@ -580,6 +603,7 @@ int main(int argc, char** argv) {
     const uint32_t tracers = argc > 5 ? (uint32_t)atoi(argv[5]) : 3, shaders = argc > 6 ? (uint32_t)atoi(argv[6]) : 2;
     const uint32_t rq_log2 = argc > 7 ? (uint32_t)atoi(argv[7]) : 3;
     m.spec = argc > 8 && atoi(argv[8]) != 0;
+    m.keep = argc > 9 ? (uint32_t)atoi(argv[9]) : 0;
     if (m.n_slots > (1u << SLOT_BITS) || m.n_slots == 0 || m.n_pixels == 0 || (m.variant != 0 && m.variant != 2 && m.variant != 3)) return 2;
     // Start-up preconditions (the kernel's are static_asserts in er_stream.hip):
     //  * a wave's reservation must fit the ray ring -- else its later puts wait for readers of its own unpublished entries: a cycle.

@@ -73,6 +73,22 @@ def test_every_ray_once_every_sample_in_order_every_ring_empty(model, cfg):
 SPEC_CONFIGS = [(16, 6, 300, 3, 3, 4), (24, 10, 200, 4, 3, 4), (12, 5, 400, 3, 3, 3), (8, 24, 200, 3, 2, 3)]
 
 
+# ... + speculative samples (0 / 1), the keep rule's slack + 1
+KEEP_CONFIGS = [(8, 24, 200, 3, 2, 3, 0, 2), (8, 24, 200, 3, 2, 3, 1, 2), (16, 40, 120, 3, 3, 4, 1, 1), (12, 30, 150, 4, 3, 3, 0, 1), (24, 10, 200, 4, 3, 4, 1, 2)]
+
+
+@pytest.mark.parametrize("cfg", KEEP_CONFIGS, ids=lambda c: "x".join(str(v) for v in c))
+def test_pixels_behind_keep_their_slots_every_sample_once_in_order(model, cfg):
+    """Round 6: a pixel that is behind the most advanced one goes on in the slot it has instead of queueing in the pixel ring
+    (csrc/er_stream.hip s_front).  In the model, with and without speculative samples beside it: every pixel's samples are still
+    accumulated once, in order and from the true stream state, every ring ends empty, and samples WERE begun in the slot their pixel had."""
+    slots, pixels, samples, tracers, shaders, rq_log2, spec, keep = cfg
+    r = _run(model, slots, pixels, samples, 0, tracers, shaders, rq_log2, spec, keep)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    assert "0 pixels short" in r.stdout and " 0 lost, 0 protocol errors, 0 ring faults" in r.stdout
+    assert int(r.stdout.split("samples begun in the slot their pixel had: ")[1].split()[0]) > 0, r.stdout
+
+
 @pytest.mark.parametrize("cfg", SPEC_CONFIGS, ids=lambda c: "x".join(str(v) for v in c))
 def test_speculative_samples_every_sample_once_in_order_from_the_true_state(model, cfg):
     """Round 6: the speculative samples of the small-share forms of the kernel (csrc/er_stream.hip ST_DRAWS_MASK) in the model: a pixel's next
@@ -93,9 +109,10 @@ def test_speculative_samples_every_sample_once_in_order_from_the_true_state(mode
 
 def test_thread_sanitizer_finds_no_unordered_hand_off(model_tsan):
     for cfg in [(8, 24, 60, 3, 2, 3, 0), (6, 40, 30, 4, 3, 2, 0), (4, 4, 300, 3, 3, 2, 0), (16, 16, 100, 6, 4, 4, 0),
-                (16, 6, 80, 3, 3, 4, 1), (24, 10, 60, 4, 3, 4, 1), (12, 5, 100, 3, 3, 3, 1)]:      # (the last three: with speculative samples)
-        slots, pixels, samples, tracers, shaders, rq_log2, spec = cfg
-        r = _run(model_tsan, slots, pixels, samples, 0, tracers, shaders, rq_log2, spec, timeout=600)
+                (16, 6, 80, 3, 3, 4, 1), (24, 10, 60, 4, 3, 4, 1), (12, 5, 100, 3, 3, 3, 1),      # (these three: with speculative samples)
+                (8, 24, 60, 3, 2, 3, 0, 2), (16, 40, 50, 3, 3, 4, 1, 1)]:                         # (the last two: with the keep rule)
+        slots, pixels, samples, tracers, shaders, rq_log2, spec = cfg[:7]
+        r = _run(model_tsan, slots, pixels, samples, 0, tracers, shaders, rq_log2, spec, *cfg[7:], timeout=600)
         assert "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
         assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
 
