@@ -594,7 +594,7 @@ def main():
             "readback_ms": round(readback_ms, 2), "gather": gather_path, "beauty_mean": beauty_mean,
             # the streaming schedule's configuration of this rank's share and its speculation counts over the render (zero on whole frames:
             # speculative samples exist in the 12-wave form only, i.e. on shares of hardly more pixels than slots)
-            "stream": (lambda si: {"pixels_per_cu": si["pixels_per_cu"], "waves": si["waves"], "tracers": si["tracers"], "large_regions": bool(si["large_regions"]), "lanes_busy": round(si["lanes_busy"], 4),
+            "stream": (lambda si: {"pixels_per_cu": si["pixels_per_cu"], "form": si["form"], "waves": si["waves"], "tracers": si["tracers"], "large_regions": bool(si["large_regions"]), "lanes_busy": round(si["lanes_busy"], 4),
                                    "speculation": {"started": si["spec_started"], "right": si["spec_right"], "wrong": si["spec_wrong"]}})(rm.stream_info()) if sched == "stream" else None,
             # N > 1: per-rank device time of the timed region (a rank whose tiles hold longer paths shows here), and the framebuffer
             # combine: wall time of the five er_gather_pass calls on the slowest rank and the bytes the root received
@@ -626,7 +626,8 @@ def main():
                                     # what the share ran as: owned pixels per CU, waves per workgroup and how many of them trace, the share of their
                                     # lanes that held a ray in the last launch (the whole frame: roofline.trace_lanes.busy of the instrumented replay),
                                     # the deal; `latency_tracer`: no second tracer role exists (priced and not built)
-                                    "pixels_per_cu": si["pixels_per_cu"], "waves": si["waves"], "tracers": si["tracers"], "lanes_busy": round(si["lanes_busy"], 4),
+                                    # `form`: 0 the whole-frame kernel, 1 pixels that are behind keep their slots, 2 that and speculative samples
+                                    "pixels_per_cu": si["pixels_per_cu"], "form": si["form"], "waves": si["waves"], "tracers": si["tracers"], "lanes_busy": round(si["lanes_busy"], 4),
                                     "large_regions": bool(si["large_regions"]), "latency_tracer": False,
                                     # round 6: speculative sample pipelining of the 12-wave form: samples started beside the
                                     # pixel's sample in flight, and how many of those guesses of the RNG state were right / wrong

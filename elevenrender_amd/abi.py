@@ -99,7 +99,8 @@ class ErAccelInfo(C.Structure):
 class ErStreamInfo(C.Structure):   # include/eleven_hip_debug.h
     _fields_ = [("waves", C.c_uint32), ("tracers", C.c_uint32), ("large_regions", C.c_uint32), ("deal_pending", C.c_uint32), ("launches", C.c_uint32),
                 ("pixels_per_cu", C.c_uint32), ("lanes_busy", C.c_double), ("launch_ms", C.c_double), ("cost_spread", C.c_double),
-                ("spec_started", C.c_uint64), ("spec_right", C.c_uint64), ("spec_wrong", C.c_uint64)]
+                ("spec_started", C.c_uint64), ("spec_right", C.c_uint64), ("spec_wrong", C.c_uint64),
+                ("form", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class ErTraceRec(C.Structure):   # include/eleven_hip_debug.h; same layout as the oracle's OracleTraceRec

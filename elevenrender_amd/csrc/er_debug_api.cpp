@@ -4,6 +4,7 @@
 // and exercise the boundary's failure paths.
 #include "er_scene.h"
 #include "er_debug.h"
+#include "er_stream.h"
 
 using namespace erh;
 
@@ -276,6 +277,9 @@ static int er_debug_stream_info_impl(ErScene* s, ErStreamInfo* out) {
     out->pixels_per_cu = (uint32_t)((size_t)s->dev.owned_tile_count * 64 / std::max<uint32_t>(1u, s->stream_blocks));
     out->lanes_busy = s->stream_busy; out->launch_ms = s->stream_launch_ms; out->cost_spread = s->stream_cost_spread;
     out->spec_started = s->stream_spec[0]; out->spec_right = s->stream_spec[1]; out->spec_wrong = s->stream_spec[2];
+    // (er_launch_stream's choice: the speculative form only for scenes it starts speculative samples in, the keep form at 16 waves)
+    const bool spec_scene = s->dev.max_bounces <= 1000u && s->tri_count >= ER_STREAM_SPEC_MIN_TRIS;
+    out->form = (s->stream_spec_form && spec_scene) ? 2u : ((s->stream_keep && s->stream_waves == 16u) ? 1u : 0u);
     return ER_OK;
 }
 

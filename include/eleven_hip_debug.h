@@ -113,6 +113,8 @@ typedef struct ErStreamInfo {
     double launch_ms;              /* device time of that launch */
     double cost_spread;            /* (max - min) / mean of the XCDs' counted work under the large deal; < 0: not decided */
     uint64_t spec_started, spec_right, spec_wrong;   /* speculative samples (small shares) started / whose guessed RNG state was right / wrong, completed launches of this render */
+    uint32_t form;                 /* the kernel's form this share is launched in: 0 plain (whole frames), 1 pixels that are behind keep their slots, 2 that and speculative samples */
+    uint32_t reserved;
 } ErStreamInfo;
 int er_debug_stream_info(struct ErScene* s, ErStreamInfo* out);
 
