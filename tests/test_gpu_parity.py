@@ -685,21 +685,26 @@ def test_speculative_samples_change_neither_the_image_nor_any_count(waves, ext, 
 
 @pytest.mark.parametrize("ext", [0, abi.FLAG_POINT_LIGHTS | abi.FLAG_MIS])
 def test_pixels_behind_keep_their_slots_and_the_image_does_not_change(ext, monkeypatch):
-    """Round 6: where a workgroup's pixels outnumber its slots (the 16-wave speculative form: a quarter or a sixth of a 1080p frame per GPU) a pixel
+    """Round 6: where a workgroup's pixels outnumber its slots (the kernel's forms 1 and 2 at 16 waves: a half ... a sixth of a 1080p frame per GPU, a 720p frame) a pixel
     that is two samples behind the workgroup's most advanced one goes on in the slot it has instead of queueing in the pixel ring
     (csrc/er_stream.hip s_front), so that the expensive pixels are not what the launch ends on.  Which slot renders a sample and when is
-    nobody's business: planes, sample counts, RNG states and every event counter equal the wavefront schedule's, with the rule on (the
-    product), off, and with a slack of one sample -- on a frame of 2 560 pixels per workgroup (2.5 per slot), where the ring is never empty
-    until the launch's end."""
+    nobody's business: planes, sample counts, RNG states and every event counter (with ER_FLAG_COUNTERS also node visits, triangle tests and
+    texel fetches) equal the wavefront schedule's, in both forms, with the rule on (the product), off, and with a slack of one sample -- on a
+    frame of 2 560 pixels per workgroup (2.5 per slot), where the ring is never empty until the launch's end."""
     sc = scenes.soup(30000, 1024, 640, seed=23, hdri_size=(128, 64))
     if ext:
         sc.point_lights = scenes.point_lights(12, seed=4)
         sc._desc = None
-    w = gpu_render(sc, 13, max_bounces=8, flags=abi.FLAG_WAVEFRONT | ext)
-    monkeypatch.setenv("ER_STREAM_SPEC_FORM", "1")
-    for keep in ("2", "0", "1"):
+    for form, keep, count in ((1, "2", 0), (1, "2", abi.FLAG_COUNTERS), (1, "1", 0), (2, "2", 0), (2, "0", 0), (2, "1", abi.FLAG_COUNTERS)):
+        # (form 1 is what a share of this size gets by itself; form 2 -- the rule beside speculative samples -- is forced here: a share of 2 304 pixels per
+        # CU or fewer gets it by itself)
+        w = gpu_render(sc, 13, max_bounces=8, flags=abi.FLAG_WAVEFRONT | ext | count)
+        if form == 2:
+            monkeypatch.setenv("ER_STREAM_SPEC_FORM", "1")
+        else:
+            monkeypatch.delenv("ER_STREAM_SPEC_FORM", raising=False)
         monkeypatch.setenv("ER_STREAM_SPEC_KEEP", keep)
-        rm = render.RenderingManager(render.RenderParameters(max_bounces=8, flags=abi.FLAG_STREAM | ext))
+        rm = render.RenderingManager(render.RenderParameters(max_bounces=8, flags=abi.FLAG_STREAM | ext | count))
         rm.start_rendering(sc)
         for n in (4, 9):
             rm.render(n)
@@ -707,10 +712,9 @@ def test_pixels_behind_keep_their_slots_and_the_image_does_not_change(ext, monke
         s = {p: rm.get_pass(p) for p in ("beauty", "normal", "tangent", "bitangent")}
         s["rng"], s["samples"], s["counters"] = rm.read_rng(), rm.read_samples(), rm.counters()
         rm.close()
-        assert si["waves"] == 16 and si["pixels_per_cu"] > 2048
+        assert si["waves"] == 16 and si["pixels_per_cu"] > 2304 and si["form"] == form, si
         for p in ("beauty", "normal", "tangent", "bitangent"):
-            assert (w[p].view(np.uint32) == s[p].view(np.uint32)).all(), (keep, p)
+            assert (w[p].view(np.uint32) == s[p].view(np.uint32)).all(), (form, keep, p)
         assert (w["rng"] == s["rng"]).all() and (w["samples"] == s["samples"]).all()
-        for k in ("paths", "bounce_samples", "rays", "shaded_hits", "hdri_samples"):
-            assert w["counters"][k] == s["counters"][k], (keep, k, w["counters"][k], s["counters"][k])
-
+        for k in ["paths", "bounce_samples", "rays", "shaded_hits", "hdri_samples"] + (["node_visits", "tri_tests", "texel_fetches"] if count else []):
+            assert w["counters"][k] == s["counters"][k], (form, keep, k, w["counters"][k], s["counters"][k])
