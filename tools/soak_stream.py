@@ -41,3 +41,25 @@ for name, sc, spp, chunks, mb in (("C2 1920x1080 x 256 spp", scenes.soup(1_000_0
     print(f"soak: {name}: default schedule in {len(chunks)} calls == wavefront bit for bit; wall time incl. scene set-up and read-back {t2 - t1:.1f} s (wavefront {t1 - t0:.1f} s), "
           f"{s['counters']['bounce_samples'] / 1e6:.0f} M samples", flush=True)
     del w, s
+# soak 5 (round 6): one GPU's share of the C2 frame at every size the kernel has a form for -- 1/2 and 1/3 (form 1: pixels that are behind keep their
+# slots), 1/4 and 1/6 (form 2 at 16 waves: that and speculative samples), 1/8 and 1/16 (form 2 at 12 waves) -- streaming schedule in uneven calls
+# against the wavefront schedule in one: planes, RNG states, sample counts and the event counters of exactly that share
+sc = scenes.soup(1_000_000, 1920, 1080, seed=12345)
+for world in (2, 3, 4, 6, 8, 16):
+    t0 = time.time()
+    w = gpu_render(sc, 40, max_bounces=8, flags=abi.FLAG_WAVEFRONT, rank=world - 1, world=world)
+    rm = render.RenderingManager(render.RenderParameters(max_bounces=8, flags=abi.FLAG_STREAM, rank=world - 1, world=world))
+    rm.start_rendering(sc)
+    for n in (1, 4, 15, 20):
+        rm.render(n)
+    si = rm.stream_info()
+    s = {p: rm.get_pass(p) for p in ("beauty", "normal", "tangent", "bitangent")}
+    s["rng"], s["samples"], s["counters"] = rm.read_rng(), rm.read_samples(), rm.counters()
+    rm.close()
+    for p in ("beauty", "normal", "tangent", "bitangent"):
+        assert (w[p].view(np.uint32) == s[p].view(np.uint32)).all(), (world, p)
+    assert (w["rng"] == s["rng"]).all() and (w["samples"] == s["samples"]).all()
+    for k in ("paths", "bounce_samples", "rays", "shaded_hits", "hdri_samples"):
+        assert w["counters"][k] == s["counters"][k], (world, k)
+    print(f"soak: rank {world - 1} of {world} of the C2 frame x 40 spp in 4 calls: form {si['form']}, {si['waves']} waves ({si['tracers']} tracers), {si['pixels_per_cu']} pixels per CU, "
+          f"speculative samples {si['spec_started']} started / {si['spec_right']} right: == wavefront bit for bit, counters equal ({s['counters']['bounce_samples'] / 1e6:.0f} M samples), {time.time() - t0:.1f} s", flush=True)
