@@ -2,7 +2,7 @@
 """Where a bounce of a path spends its time in the streaming schedule, stage by stage (closest-hit rays only).
 
 Needs the diagnostic build:  make -C elevenrender_amd/csrc BUILD=build_sp OUT=../libeleven_sp.so EXTRA=-DER_STAGE_PROBE
-and runs on the GPU box:     ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_sp.so python3 tools/stage_probe.py [passes] [world]
+and runs on the GPU box:     ELEVEN_HIP_LIB=$PWD/elevenrender_amd/libeleven_sp.so python3 tools/stage_probe.py [passes] [world] [C2|C4|C5|C5nl]
 In that build every closest-hit ray is stamped (10-ns ticks) when a shader wave queues it (A), when a tracer lane takes it (B), when
 its traversal ends (C), when the tracer publishes it (D), when a shader wave starts the slot's next step (E) and when that step has
 queued the next ray (F); the event counters carry the sums."""
@@ -10,15 +10,18 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # (the repo root: elevenrender_amd, bench)
 from elevenrender_amd import abi, render, scenes
 
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     world = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    sc = scenes.soup(1_000_000, 1920, 1080, seed=12345)
-    rm = render.RenderingManager(render.RenderParameters(max_bounces=8, rank=0, world=world, flags=abi.FLAG_STREAM))
+    cfg = sys.argv[3] if len(sys.argv) > 3 else "C2"      # C2 | C4 | C5 (with lights + MIS) | C5nl: bench.py's scenes
+    import argparse
+    import bench
+    sc, ext, _ = bench.make_scene(argparse.Namespace(config=cfg[:2], width=0, height=0, tris=1_000_000, blob_tris=1000, no_lights=cfg == "C5nl"), scenes, abi)
+    rm = render.RenderingManager(render.RenderParameters(max_bounces=bench.CONFIGS[cfg[:2]][1], rank=0, world=world, flags=abi.FLAG_STREAM | ext))
     rm.start_rendering(sc)
     rm.render(2)
     c0 = rm.counters()
@@ -33,7 +36,7 @@ def main():
     names = ["A->B  queued by a shader wave -> taken by a tracer lane (ray ring)", "B->C  traversal", "C->D  finished -> published (the wave's next ring visit)",
              "D->E  published -> the slot's next step starts (its other rays, the shade / finish ring, a free shader wave)", "E->F  the step, until the next ray is queued"]
     px = sc.x_res * sc.y_res // world // 256
-    print(f"C2{'' if world == 1 else f', rank 0 of {world}'} ({px} pixels per CU): {n} passes in {wall * 1e3:.1f} ms ({wall * 1e3 / n:.3f} ms per pass); {rays} closest-hit rays stamped")
+    print(f"{cfg}{'' if world == 1 else f', rank 0 of {world}'} ({px} pixels per CU): {n} passes in {wall * 1e3:.1f} ms ({wall * 1e3 / n:.3f} ms per pass); {rays} closest-hit rays stamped")
     tot = 0.0
     for nm, v in zip(names, d[:5]):
         us = v / rays * 0.01
