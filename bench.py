@@ -593,7 +593,7 @@ def main():
                         "region_ms": [round(r["kernel_ms"], 3) for r in reps], "elapsed_ms": [round(e * 1e3, 3) for e in rep_elapsed]},
             "readback_ms": round(readback_ms, 2), "gather": gather_path, "beauty_mean": beauty_mean,
             # the streaming schedule's configuration of this rank's share and its speculation counts over the render (zero on whole frames:
-            # speculative samples exist in the 12-wave form only, i.e. on shares of hardly more pixels than slots)
+            # speculative samples exist in the kernel's form 2 only, i.e. on shares of at most 2 304 pixels per CU)
             "stream": (lambda si: {"pixels_per_cu": si["pixels_per_cu"], "form": si["form"], "waves": si["waves"], "tracers": si["tracers"], "large_regions": bool(si["large_regions"]), "lanes_busy": round(si["lanes_busy"], 4),
                                    "speculation": {"started": si["spec_started"], "right": si["spec_right"], "wrong": si["spec_wrong"]}})(rm.stream_info()) if sched == "stream" else None,
             # N > 1: per-rank device time of the timed region (a rank whose tiles hold longer paths shows here), and the framebuffer
@@ -629,7 +629,7 @@ def main():
                                     # `form`: 0 the whole-frame kernel, 1 pixels that are behind keep their slots, 2 that and speculative samples
                                     "pixels_per_cu": si["pixels_per_cu"], "form": si["form"], "waves": si["waves"], "tracers": si["tracers"], "lanes_busy": round(si["lanes_busy"], 4),
                                     "large_regions": bool(si["large_regions"]), "latency_tracer": False,
-                                    # round 6: speculative sample pipelining of the 12-wave form: samples started beside the
+                                    # round 6: speculative sample pipelining of the kernel's form 2 (DESIGN.md sections 5 and 7): samples started beside the
                                     # pixel's sample in flight, and how many of those guesses of the RNG state were right / wrong
                                     "speculation": {"started": si["spec_started"], "right": si["spec_right"], "wrong": si["spec_wrong"]}}
                 except abi.ErError as e:
