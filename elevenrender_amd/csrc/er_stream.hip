@@ -1319,6 +1319,8 @@ void er_launch_stream(const DevScene& S, const DevScene* S_dev, void* records, u
     // (iterations x 16; the field holds up to 511: longer paths, no such pixels.  12-wave form only: 1/16 share of the C2 frame - 5 %, 1/8 - 0 ... 2 %; the 16-wave form's 1/4 share + 0.6 %)
     const uint32_t long_thr = waves == 12u ? S.max_bounces * spec_long16 : 0u;
     const uint32_t spec_now = (S.max_bounces <= 1000u && S.tri_count >= ER_STREAM_SPEC_MIN_TRIS) ? (spec_flag | ((long_thr > 511u ? 0u : long_thr) << 20) | (((waves == 16u && keep) ? spec_keep : 0u) << 29)) : 0u;      // (the 16-wave form, whose pixels outnumber its slots: 1/4 share - 3.7 ... 5 %, 1/6 - 1 %; the 12-wave form's 1/8 ... 1/16 shares +- 0 ... + 1 %)
+    // (the kernel's last argument, one word: bits 0-7 the finishing batch's minimum; forms 1 and 2: bits 29-31 the keep rule's slack + 1; form 2: bits 8-10 the
+    // confidence a guess needs, 12-19 the idle polls a shader wave must have behind it before it starts speculative samples, 20-28 the long pixels' mean path x 16)
     const uint32_t keep_plain = (keep && waves == 16u) ? (spec_keep << 29) : 0u;
     if (tracers > ST_MAX_TRACERS) tracers = ST_MAX_TRACERS;      // (the LDS traversal stacks are sized for that many; at least 3 shader waves stay)
     waves = waves == 12u ? 12u : 16u;
