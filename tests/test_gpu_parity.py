@@ -718,3 +718,25 @@ def test_pixels_behind_keep_their_slots_and_the_image_does_not_change(ext, monke
         assert (w["rng"] == s["rng"]).all() and (w["samples"] == s["samples"]).all()
         for k in ["paths", "bounce_samples", "rays", "shaded_hits", "hdri_samples"] + (["node_visits", "tri_tests", "texel_fetches"] if count else []):
             assert w["counters"][k] == s["counters"][k], (form, keep, k, w["counters"][k], s["counters"][k])
+
+
+def test_a_share_of_a_1080p_frame_gets_the_form_made_for_its_size():
+    """Round 6 (csrc/er_api.cpp, er_stream.h): the streaming kernel has three forms and two wave counts, picked by a rank's owned pixels per CU --
+    the whole frame (8 100): form 0, 16 waves, 13 tracers (round 5's code); a half (4 050): form 1 (pixels that are behind keep their slots); a
+    quarter (2 025): form 2 (that and speculative samples), 16 waves; an eighth (1 012): form 2 in 12 waves, 10 of them tracers; a sixteenth
+    (506): 9 tracers.  A scene of fewer than 1 000 triangles starts no speculative samples whatever its share."""
+    sc = scenes.soup(20000, 1920, 1080, seed=3, hdri_size=(64, 32))
+    want = {1: (0, 16, 13), 2: (1, 16, 13), 4: (2, 16, 13), 8: (2, 12, 10), 16: (2, 12, 9)}
+    for world, (form, waves, tracers) in want.items():
+        rm = render.RenderingManager(render.RenderParameters(max_bounces=3, flags=abi.FLAG_STREAM, rank=0, world=world))
+        rm.start_rendering(sc)
+        rm.render(2)
+        si = rm.stream_info()
+        rm.close()
+        assert (si["form"], si["waves"], si["tracers"]) == (form, waves, tracers), (world, si)
+    rm = render.RenderingManager(render.RenderParameters(max_bounces=3, flags=abi.FLAG_STREAM, rank=0, world=8))
+    rm.start_rendering(scenes.cornell(1920, 1080))
+    rm.render(2)
+    si = rm.stream_info()
+    rm.close()
+    assert si["form"] == 0 and si["spec_started"] == 0, si
